@@ -1,0 +1,183 @@
+/*
+ * v3d_hip.h — C ABI of libv3d_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels behind the
+ * V3D dense-multi-view hot path (EulerEDM loop -> VideoUNet -> VideoDecoder).
+ *
+ * The reference (heheyas/V3D) has no native layer: every device op on this path is a PyTorch ATen /
+ * xformers call made from Python.  Each entry point below therefore names the *reference call site*
+ * whose device work it replaces (paths relative to the reference tree).  The Python plugin classes in
+ * v3d_amd/sgm/ (same `target:` API as the reference sgm/ package) are the only callers.
+ *
+ * Conventions
+ *   - every entry returns 0 on success, <0 on error; v3d_last_error() gives a thread-local message
+ *   - all pointers are DEVICE pointers on the current device; the caller allocates every output
+ *   - kernels are stateless and re-entrant per stream; `stream` is a hipStream_t passed as void*
+ *   - activations are bf16, "channels last": act[n_img][H*W][C] row-major; n_img = (cfg*B*T) ordered (b t)
+ *   - weights are bf16, K-contiguous: W[taps][N][K]; vectors (bias, norm affine, per-image adds) are fp32
+ *   - all matrix contractions accumulate in fp32 on MFMA; norm statistics are fp32
+ */
+#ifndef V3D_HIP_H
+#define V3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V3D_ABI_VERSION 1
+
+typedef void* v3d_stream_t; /* hipStream_t */
+
+enum {
+    V3D_OK = 0,
+    V3D_ERR_ARG = -1,    /* bad argument (shape / alignment / null pointer) */
+    V3D_ERR_LAUNCH = -2, /* HIP launch failure */
+};
+
+int v3d_abi_version(void);
+const char* v3d_last_error(void);
+/* Device properties of the current device: out[0]=CU count, out[1]=LDS bytes/CU (as reported), out[2]=wave size, out[3]=gfx arch number (950) */
+int v3d_device_info(int32_t* out4);
+
+/* ------------------------------------------------------------------------------------------------
+ * v3d_gemm — multi-tap MFMA contraction with fused epilogue.
+ *
+ *   acc[m][n] = sum_{tap} sum_{k<K} A[src(m, tap)][k] * W[tap][n][k]          (fp32 accumulate)
+ *   v         = acc + bias[n] + add[(m / add_rpg) * add_ld + n]
+ *   if geglu:   v = v_value * gelu_erf(v_gate)        (W rows packed in 16-row value/gate groups, N_out = N/2)
+ *   out[m][n] = c_acc * v + c_res1 * res1[m][n] + c_res2 * res2[m][n]         (bf16 or fp32 store)
+ *   (c_* come from coef[(m / coef_rpg)*3 + {0,1,2}] when coef != NULL, else from the scalar fields)
+ *
+ * mode V3D_GEMM_LINEAR : 1 tap, src(m) = m.
+ *      replaces nn.Linear / 1x1 Conv2d:  sgm/modules/attention.py:95-118,277-283,692-704;
+ *      sgm/modules/video_attention.py:50-71,219-224; sgm/modules/diffusionmodules/openaimodel.py:294-300,324;
+ *      sgm/modules/diffusionmodules/model.py:161-172 (VAE q/k/v/proj 1x1); batched form = the two SDPA
+ *      GEMMs of the VAE AttnBlock (model.py:180-201).
+ * mode V3D_GEMM_CONV3X3: 9 taps (ky,kx) row-major; rows are output pixels (img, oy, ox) of an Hout x Wout map;
+ *      input pixel = (oy*stride + ky - 1, ox*stride + kx - 1) in the logical input of size (Hin*up) x (Win*up),
+ *      zero outside; up=2 reads the nearest-neighbour 2x upsample of the stored Hin x Win map on the fly.
+ *      replaces Conv2d 3x3 pad 1 (openaimodel.py:270,307-313; video_model.py:189,439; model.py:111-119),
+ *      Downsample stride 2 (openaimodel.py:202-209), Upsample nearest+conv (openaimodel.py:164-166; model.py:67-71).
+ * mode V3D_GEMM_CONVT3 : 3 taps along the frame axis; rows are (frame, s) with S rows per frame; tap dt reads
+ *      row m + (dt-1)*S when tmin <= (frame % T) + dt - 1 <= tmax, else zero.
+ *      replaces Conv3d (3,1,1) pad (1,0,0) (video_model.py:42-55 via openaimodel.py:267-313; temporal_ae.py:32-44).
+ *      With frame sharding the caller points A at a buffer carrying +-1 halo frames and widens [tmin,tmax].
+ * ---------------------------------------------------------------------------------------------- */
+enum { V3D_GEMM_LINEAR = 0, V3D_GEMM_CONV3X3 = 1, V3D_GEMM_CONVT3 = 2 };
+
+typedef struct v3d_gemm_args {
+    const void* A;      /* bf16 [rows][lda] */
+    const void* W;      /* bf16 [taps][N][K] */
+    void* out;          /* bf16 or fp32 [M][ldo] */
+    const float* bias;  /* [N] or NULL (packed order when geglu) */
+    const float* add;   /* row-group vectors or NULL */
+    const void* res1;   /* bf16 [M][ldr1] or NULL */
+    const void* res2;   /* bf16 [M][ldr2] or NULL */
+    const float* coef;  /* [groups][3] or NULL */
+    int64_t M, N, K;    /* N = rows of W per tap (2*N_out when geglu); K = contraction per tap, K % 8 == 0 */
+    int64_t lda, ldo, ldr1, ldr2;
+    int64_t a_rows;     /* rows of A addressable behind the pointer (hardware bounds check; < 4 GiB total) */
+    int64_t a_row0;     /* row offset added to every source row (CONVT3 halo frames in front of frame 0), >= 0 */
+    int64_t add_rpg, add_ld; /* rows per add group, stride (floats) between groups' vectors */
+    int64_t coef_rpg;
+    float c_acc, c_res1, c_res2;
+    int32_t mode, geglu, out_fp32;
+    int32_t Hin, Win, Hout, Wout, stride, up; /* CONV3X3 */
+    int32_t T, tmin, tmax;                    /* CONVT3 (S = rows per frame) */
+    int64_t S;
+    int32_t batch;                            /* >= 1; grid.y */
+    int64_t sA, sW, sO;                       /* element strides between batches (A, W, out) */
+} v3d_gemm_args;
+
+int v3d_gemm(const v3d_gemm_args* args, v3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm (32 groups) over channels-last activations, optionally over two channel-concatenated sources
+ * (the U-Net skip concat th.cat([h, hs.pop()], 1) at video_model.py:483 is never materialised).
+ *   stats[g_img][group][2] += (sum, sumsq) over rows of the images in that stat group  (fp32 atomics; caller zeroes)
+ *   imgs_per_stat = 1 for 2-D GroupNorm, = frames-per-sample for the 3-D GroupNorm whose statistics span
+ *   all frames (openaimodel.py:267-271,302-305 with dims=3).  Under frame sharding the caller all-reduces `stats`.
+ *   apply: y = (x - mean) * rstd * gamma + beta, mean/var from stats and `count` (elements per group, global),
+ *   then SiLU when silu != 0; bf16 out [n_img*S][C1+C2].
+ * replaces GroupNorm32 / Normalize (+SiLU / swish): diffusionmodules/util.py:259-276; attention.py:130-133;
+ *   model.py:52-55,43-45; openaimodel.py:267-271,302-305.
+ * ---------------------------------------------------------------------------------------------- */
+int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats,
+                        int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, v3d_stream_t stream);
+int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* stats,
+                        const float* gamma, const float* beta, void* out, int64_t n_img, int64_t S,
+                        int32_t groups, int64_t imgs_per_stat, double count, float eps, int32_t silu,
+                        v3d_stream_t stream);
+
+/* LayerNorm over the last dim of bf16 [M][C]; optional fp32 row-group vector added first:
+ *   xs = x + add[(m / add_rpg) * add_ld + c];  if xsum_out: xsum_out[m] = bf16(xs);  out = LN(xs)*gamma + beta
+ * replaces nn.LayerNorm (attention.py:525-527; video_attention.py:51,79,93-94) and the frame-position add
+ * `x_mix = x + emb` (video_attention.py:286-287). */
+int v3d_layernorm(const void* x, const float* add, int64_t add_rpg, int64_t add_ld, void* xsum_out,
+                  const float* gamma, const float* beta, void* out, int64_t M, int64_t C, float eps,
+                  v3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spatial self-attention, head dim 64, no mask: out[n][s][h*64+d] = softmax(q k^T * scale) v.
+ *   q[n][s][h*64+d] at q + (n*S+s)*ldq ; k likewise at k + (n*S+s)*ldk ; vT[n][h*64+d][s] (keys contiguous).
+ * replaces F.scaled_dot_product_attention / xformers.ops.memory_efficient_attention in
+ *   CrossAttention.forward (attention.py:337-341) / MemoryEfficientCrossAttention.forward (attention.py:432-444)
+ *   for BasicTransformerBlock.attn1 (attention.py:559-569).
+ * ---------------------------------------------------------------------------------------------- */
+int v3d_attn_spatial(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vT, void* out,
+                     int64_t ldo, int64_t n_img, int64_t S, int32_t heads, float scale, v3d_stream_t stream);
+
+/* Temporal self-attention over the frame axis (Tq local queries x Tk keys, Tq,Tk <= 32), head dim 64.
+ *   problem p = (b, s, h); element (b, t, s, h*64+d) of q at q + b*q_sb + t*q_st + s*q_ss + h*64 + d (same for k, v, out).
+ * replaces VideoTransformerBlock.attn1 on "(b t) s c -> (b s) t c" (video_attention.py:114,122-125) without the
+ * two full-tensor transposes. */
+int v3d_attn_temporal(const void* q, int64_t q_sb, int64_t q_st, int64_t q_ss,
+                      const void* k, const void* v, int64_t kv_sb, int64_t kv_st, int64_t kv_ss,
+                      void* out, int64_t o_sb, int64_t o_st, int64_t o_ss,
+                      int64_t B, int32_t Tq, int32_t Tk, int64_t S, int32_t heads, float scale,
+                      v3d_stream_t stream);
+
+/* Row softmax: out_bf16[r][j] = softmax_j(in_f32[r][:]) ; used by the VAE AttnBlock (model.py:190-192) in
+ * its unfused (batched GEMM -> softmax -> batched GEMM) form. */
+int v3d_softmax_rows(const float* in, void* out, int64_t rows, int64_t L, v3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small elementwise kernels
+ * ---------------------------------------------------------------------------------------------- */
+/* sinusoidal embedding [cos | sin], freqs exp(-ln(max_period) * i / half)  (diffusionmodules/util.py:207-231) */
+int v3d_timestep_embedding(const float* t, void* out_bf16, int64_t n, int32_t dim, float max_period, v3d_stream_t stream);
+/* out_bf16 = silu(in_f32 [+ in2_f32]) : emb = time_embed(..) + label_emb(..) then nn.SiLU of emb_layers (openaimodel.py:294-300) */
+int v3d_silu_add(const float* in, const float* in2, void* out_bf16, int64_t n, v3d_stream_t stream);
+/* EDM v-prediction scalings (denoiser_scaling.py:51-59): c_skip, c_out, c_in, c_noise per image */
+int v3d_edm_scalings(const float* sigma, float* c_skip, float* c_out, float* c_in, float* c_noise, int64_t n, v3d_stream_t stream);
+/* U-Net input assembly: out_bf16[n][s][c] = c<C1 ? x[n][c][s]*scale[n] : cond[n][c-C1][s], zero-padded to Cpad
+ * (denoiser.py:36-37 `input * c_in`, wrappers.py:27 torch.cat((x, c["concat"]), 1), NCHW fp32 -> channels-last bf16) */
+int v3d_pack_input(const float* x, const float* scale, int64_t C1, const float* cond, int64_t C2, void* out_bf16,
+                   int64_t n, int64_t S, int64_t Cpad, v3d_stream_t stream);
+/* denoised[n][c][s] = net[n][s][c] * c_out[n] + x[n][c][s] * c_skip[n]   (denoiser.py:36-39; net is fp32 channels-last, ld = ldn) */
+int v3d_denoise_combine(const float* net, int64_t ldn, const float* x, const float* c_out, const float* c_skip,
+                        float* out, int64_t n, int64_t C, int64_t S, v3d_stream_t stream);
+/* CFG with per-frame scale (guiders.py:78-86): out[i] = xu[i] + scale[i % T] * (xc[i] - xu[i]), xu = x[:n], xc = x[n:] */
+int v3d_cfg_combine(const float* x, const float* scale, float* out, int64_t n, int64_t T, int64_t chw, v3d_stream_t stream);
+/* Euler step (sampling.py:96-110, sampling_utils.py:34-35): d = (x - den)/sigma[n]; out = x + (next[n]-sigma[n])*d */
+int v3d_euler_step(const float* x, const float* den, const float* sigma, const float* next_sigma, float* out,
+                   int64_t n, int64_t chw, v3d_stream_t stream);
+/* x[n][...] *= s  (sampling.py:50) ; generic y = a*x + b on fp32 */
+int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream);
+/* AlphaBlender coefficients (diffusionmodules/util.py:341-369): for mixer i with alpha_i = sigmoid(mix_factor_i)
+ * and image g: a = ioi[g] ? 1 : alpha_i ; kind 0 (VideoResBlock): (1-a, 1, 0) ; kind 1 (SpatialVideoTransformer): (1-a, 1-a, a)
+ * out[i][g][3] */
+int v3d_blend_coefs(const float* alpha, const int32_t* kind, const float* ioi, float* out, int64_t n_mixers, int64_t n_img, v3d_stream_t stream);
+/* layout / dtype moves: fp32 NCHW <-> bf16 channels-last (zero-pad channels up to Cpad) */
+int v3d_nchw_to_nhwc_bf16(const float* x, float scale, void* out_bf16, int64_t n, int64_t C, int64_t S, int64_t Cpad, v3d_stream_t stream);
+/* AE3DConv.time_mix_conv (temporal_ae.py:94-107): Conv3d (3,1,1) on Cc<=4 channels over frames of a fp32 channels-last
+ * [B*T][S][ld] map, output fp32 NCHW [B*T][Cc][S]; w[co][ci][3], b[co]; tmin/tmax as in CONVT3 */
+int v3d_tmix_small(const float* x, int64_t ld, const float* w, const float* b, float* out, int64_t B, int32_t T,
+                   int64_t S, int32_t Cc, int32_t tmin, int32_t tmax, v3d_stream_t stream);
+/* dst_bf16[r][dst_off + c] = src_bf16[r][src_off + c], c < C  (strided 2-D bf16 copy; C % 8 == 0) */
+int v3d_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t C, v3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V3D_HIP_H */

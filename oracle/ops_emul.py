@@ -1,0 +1,231 @@
+"""TEST INFRASTRUCTURE — torch restatement of every C-ABI operator in include/v3d_hip.h.
+
+Same primitive names, argument meaning and storage dtypes as v3d_amd.hip.HipOps, but computed with plain
+fp32 torch ops on whatever device the tensors live on (CPU in the `-m "not gpu"` suite, the GPU when it is the
+per-op checker for the HIP kernels).  Used only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
+Semantics follow the op contracts in include/v3d_hip.h, which cite the reference call sites they replace.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from v3d_amd.ops import GEMM_CONV3X3, GEMM_CONVT3, GEMM_LINEAR, GemmCall, OpsBase
+
+
+class EmulOps(OpsBase):
+    name = "emul"
+
+    def __init__(self, device="cpu"):
+        self.device = torch.device(device)
+
+    # ---- v3d_gemm ---------------------------------------------------------------------------------
+    def _gemm_acc(self, g: GemmCall, A, W):
+        K, N, M = g.K, g.N, g.M
+        if g.mode == GEMM_LINEAR:
+            return A[:M, :K].float() @ W.reshape(N, K).float().t()
+        if g.mode == GEMM_CONV3X3:
+            n_img = M // (g.Hout * g.Wout)
+            x = A[: n_img * g.Hin * g.Win, :K].float().reshape(n_img, g.Hin, g.Win, K).permute(0, 3, 1, 2)
+            if g.up == 2:
+                x = F.interpolate(x, scale_factor=2, mode="nearest")
+            w = W.reshape(3, 3, N, K).permute(2, 3, 0, 1).float()
+            y = F.conv2d(x, w, stride=g.stride, padding=1)
+            assert y.shape[2] == g.Hout and y.shape[3] == g.Wout, (y.shape, g.Hout, g.Wout)
+            return y.permute(0, 2, 3, 1).reshape(M, N)
+        if g.mode == GEMM_CONVT3:
+            Af = A[:, :K].float()
+            w = W.reshape(3, N, K).float()
+            m = torch.arange(M, device=A.device)
+            t = (m // g.S) % g.T
+            acc = torch.zeros(M, N, dtype=torch.float32, device=A.device)
+            for dt in range(3):
+                tt = t + dt - 1
+                valid = (tt >= g.tmin) & (tt <= g.tmax)
+                src = m + g.a_row0 + (dt - 1) * g.S
+                src = torch.where(valid, src, torch.zeros_like(src))
+                rows = Af[src] * valid[:, None].float()
+                acc += rows @ w[dt].t()
+            return acc
+        raise ValueError(g.mode)
+
+    def gemm(self, g: GemmCall):
+        for z in range(g.batch):
+            A = g.A[z] if (g.batch > 1 and g.A.dim() == 3) else g.A
+            W = g.W[z] if (g.batch > 1 and g.W.dim() == 3 and g.mode == GEMM_LINEAR) else g.W
+            out = g.out[z] if (g.batch > 1) else g.out
+            M, N = g.M, g.N
+            v = self._gemm_acc(g, A, W)
+            if g.bias is not None:
+                v = v + g.bias.float()[None, :]
+            if g.add is not None:
+                rows = torch.arange(M, device=v.device) // g.add_rpg
+                idx = rows[:, None] * g.add_ld + torch.arange(N, device=v.device)[None, :]
+                v = v + g.add.reshape(-1)[idx]
+            if g.geglu:
+                v4 = v.reshape(M, N // 32, 2, 16)
+                v = (v4[:, :, 0, :] * F.gelu(v4[:, :, 1, :])).reshape(M, N // 2)
+            ca, c1, c2 = g.c_acc, g.c_res1, g.c_res2
+            if g.coef is not None:
+                grp = torch.arange(M, device=v.device) // g.coef_rpg
+                cf = g.coef.reshape(-1, 3)[grp]
+                ca, c1, c2 = cf[:, 0:1], cf[:, 1:2], cf[:, 2:3]
+            o = ca * v
+            if g.res1 is not None:
+                o = o + c1 * g.res1[:M].float()
+            if g.res2 is not None:
+                o = o + c2 * g.res2[:M].float()
+            out[:M].copy_(o.to(out.dtype))
+
+    # ---- norms ------------------------------------------------------------------------------------
+    @staticmethod
+    def _cat(x1, x2):
+        return x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+
+    def groupnorm_stats(self, x1, x2, stats, n_img, S, groups, imgs_per_stat):
+        x = self._cat(x1, x2).float()
+        C = x.shape[-1]
+        xg = x.reshape(n_img // imgs_per_stat, imgs_per_stat * S, groups, C // groups)
+        stats[..., 0] += xg.sum(dim=(1, 3))
+        stats[..., 1] += (xg * xg).sum(dim=(1, 3))
+
+    def groupnorm_apply(self, x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu):
+        x = self._cat(x1, x2).float()
+        C = x.shape[-1]
+        mean = stats[..., 0] / count
+        var = (stats[..., 1] / count - mean * mean).clamp_min(0)
+        rstd = torch.rsqrt(var + eps)
+        xg = x.reshape(n_img // imgs_per_stat, imgs_per_stat * S, groups, C // groups)
+        y = (xg - mean[:, None, :, None]) * rstd[:, None, :, None]
+        y = y.reshape(n_img * S, C) * gamma.float()[None, :] + beta.float()[None, :]
+        if silu:
+            y = y * torch.sigmoid(y)
+        out.copy_(y.to(out.dtype))
+
+    def layernorm(self, x, gamma, beta, out, eps, add=None, add_rpg=0, add_ld=0, xsum_out=None):
+        C = x.shape[-1]
+        xf = x.reshape(-1, C).float()
+        M = xf.shape[0]
+        if add is not None:
+            rows = torch.arange(M, device=x.device) // add_rpg
+            idx = rows[:, None] * add_ld + torch.arange(C, device=x.device)[None, :]
+            xf = xf + add.reshape(-1)[idx]
+            if xsum_out is not None:
+                xs = xf.to(torch.bfloat16)
+                xsum_out.reshape(-1, C).copy_(xs)
+                xf = xs.float()
+        y = F.layer_norm(xf, (C,), gamma.float(), beta.float(), eps)
+        out.reshape(-1, C).copy_(y.to(out.dtype))
+
+    # ---- attention --------------------------------------------------------------------------------
+    def attn_spatial(self, q, k, vT, out, n_img, S, heads, scale):
+        C = heads * 64
+        qf = q[:, :C].float().reshape(n_img, S, heads, 64).permute(0, 2, 1, 3)
+        kf = k[:, :C].float().reshape(n_img, S, heads, 64).permute(0, 2, 1, 3)
+        vf = vT.float().reshape(n_img, heads, 64, S).permute(0, 1, 3, 2)
+        o = F.scaled_dot_product_attention(qf, kf, vf, scale=scale)
+        out[:, :C].copy_(o.permute(0, 2, 1, 3).reshape(n_img * S, C).to(out.dtype))
+
+    def attn_temporal(self, q, k, v, out, heads, scale):
+        B, Tq, S, C = q.shape
+        Tk = k.shape[1]
+        qf = q.float().reshape(B, Tq, S, heads, 64).permute(0, 2, 3, 1, 4)   # b s h t d
+        kf = k.float().reshape(B, Tk, S, heads, 64).permute(0, 2, 3, 1, 4)
+        vf = v.float().reshape(B, Tk, S, heads, 64).permute(0, 2, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qf, kf, vf, scale=scale)           # b s h tq d
+        out.copy_(o.permute(0, 3, 1, 2, 4).reshape(B, Tq, S, C).to(out.dtype))
+
+    def softmax_rows(self, inp, out):
+        out.copy_(torch.softmax(inp.float(), dim=-1).to(out.dtype))
+
+    # ---- small elementwise ------------------------------------------------------------------------
+    def timestep_embedding(self, t, dim, max_period=10000.0):
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        args = t.float()[:, None] * freqs[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        if dim % 2:
+            emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+        return emb.to(torch.bfloat16)
+
+    def silu_add(self, a, b=None):
+        v = a.float() if b is None else a.float() + b.float()
+        return (v * torch.sigmoid(v)).to(torch.bfloat16)
+
+    def edm_scalings(self, sigma):
+        s = sigma.float()
+        d = s * s + 1.0
+        return 1.0 / d, -s / d.sqrt(), 1.0 / d.sqrt(), 0.25 * s.log()
+
+    def pack_input(self, x, scale, cond, Cpad):
+        n, C1 = x.shape[0], x.shape[1]
+        xs = x.float().reshape(n, C1, -1)
+        S = xs.shape[-1]
+        if scale is not None:
+            xs = xs * scale.float()[:, None, None]
+        parts = [xs]
+        if cond is not None:
+            parts.append(cond.float().reshape(n, cond.shape[1], S))
+        full = torch.cat(parts, dim=1)
+        if full.shape[1] < Cpad:
+            full = torch.cat([full, torch.zeros(n, Cpad - full.shape[1], S, device=x.device)], dim=1)
+        return full.permute(0, 2, 1).reshape(n * S, Cpad).to(torch.bfloat16)
+
+    def denoise_combine(self, net, x, c_out, c_skip):
+        n, C = x.shape[0], x.shape[1]
+        S = x.numel() // (n * C)
+        nf = net[:, :C].float().reshape(n, S, C).permute(0, 2, 1).reshape(x.shape)
+        shp = (n,) + (1,) * (x.dim() - 1)
+        return nf * c_out.reshape(shp) + x.float() * c_skip.reshape(shp)
+
+    def cfg_combine(self, x, scale, T):
+        n = x.shape[0] // 2
+        xu, xc = x[:n].float(), x[n:].float()
+        sc = scale.float()[torch.arange(n, device=x.device) % T].reshape((n,) + (1,) * (x.dim() - 1))
+        return xu + sc * (xc - xu)
+
+    def euler_step(self, x, den, sigma, next_sigma):
+        shp = (x.shape[0],) + (1,) * (x.dim() - 1)
+        d = (x - den) / sigma.reshape(shp)
+        return x + (next_sigma - sigma).reshape(shp) * d
+
+    def axpb_f32(self, x, a, b=0.0, out=None):
+        r = x * a + b
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def blend_coefs(self, alpha, kind, ioi, n_img):
+        nm = alpha.numel()
+        a = alpha.float()[:, None].expand(nm, n_img).clone()
+        if ioi is not None:
+            a = torch.where(ioi.reshape(1, n_img) != 0, torch.ones_like(a), a)
+        out = torch.empty(nm, n_img, 3, dtype=torch.float32, device=alpha.device)
+        k0 = (kind == 0)[:, None]
+        out[..., 0] = 1 - a
+        out[..., 1] = torch.where(k0, torch.ones_like(a), 1 - a)
+        out[..., 2] = torch.where(k0, torch.zeros_like(a), a)
+        return out
+
+    def nchw_to_nhwc_bf16(self, x, scale, Cpad):
+        return self.pack_input(x.float() * scale, None, None, Cpad)
+
+    def tmix_small(self, x, w, b, B, T, S, Cc, tmin, tmax):
+        xf = x[:, :Cc].float().reshape(B * T, S, Cc)
+        out = torch.zeros(B * T, Cc, S, dtype=torch.float32, device=x.device)
+        f = torch.arange(B * T, device=x.device)
+        t = f % T
+        for dt in range(3):
+            tt = t + dt - 1
+            valid = ((tt >= tmin) & (tt <= tmax)).float()
+            src = (f + dt - 1).clamp(0, B * T - 1)
+            xs = xf[src] * valid[:, None, None]                        # [f, s, ci]
+            out += torch.einsum("fsi,oi->fos", xs, w[:, :, dt].float())
+        return out + b.float()[None, :, None]
+
+    def copy2d_bf16(self, src, dst):
+        dst.copy_(src)
+        return dst

@@ -1,0 +1,272 @@
+"""Per-operator parity cases: HIP kernel (v3d_amd.hip.HipOps, through the C ABI) vs the torch restatement of
+the same op (oracle/ops_emul.py) on identical seeded inputs.  Shared by tests/test_ops_gpu.py (pytest, -m gpu)
+and tools/gpu_check.py (prints the whole table without stopping at the first failure).
+
+Tolerance: bf16 kernels vs fp32 restatement: max|err| / max|ref| <= 2e-2 and cosine >= 0.999;
+fp32 elementwise ops: 1e-5.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from v3d_amd.ops import GEMM_CONV3X3, GEMM_CONVT3, GEMM_LINEAR, GemmCall
+
+BF, F32 = torch.bfloat16, torch.float32
+TOL_BF16 = 2e-2
+TOL_F32 = 1e-5
+
+
+def _rand(gen, shape, dtype=BF, scale=1.0, device="cuda"):
+    return (torch.randn(shape, generator=gen, device="cpu", dtype=torch.float32) * scale).to(device=device, dtype=dtype)
+
+
+def compare(a: torch.Tensor, b: torch.Tensor):
+    a, b = a.float().flatten(), b.float().flatten()
+    if not torch.isfinite(a).all():
+        return float("inf"), 0.0
+    denom = b.abs().max().clamp_min(1e-12)
+    rel = ((a - b).abs().max() / denom).item()
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item() if b.abs().max() > 0 else 1.0
+    return rel, cos
+
+
+# ------------------------------------------------------------------------------------------------
+def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=True, add=False, res=0, coef=False,
+              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True):
+    g = torch.Generator().manual_seed(seed)
+    kw = {}
+    n_out = N // 2 if geglu else N
+    taps = {GEMM_LINEAR: 1, GEMM_CONV3X3: 9, GEMM_CONVT3: 3}[mode]
+    if mode == GEMM_CONV3X3:
+        n_img, Hin, Win, stride, up = conv
+        Hout, Wout = (Hin * up + 2 - 3) // stride + 1, (Win * up + 2 - 3) // stride + 1
+        a_rows = n_img * Hin * Win
+        M = n_img * Hout * Wout
+        kw.update(Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, up=up)
+    elif mode == GEMM_CONVT3:
+        B, T, S, halo, tmin, tmax = convt
+        M = B * T * S
+        a_rows = M + 2 * halo * S
+        kw.update(T=T, S=S, tmin=tmin, tmax=tmax, a_row0=halo * S)
+    else:
+        a_rows = M
+    lda = K + lda_pad
+    if batch > 1:
+        A = _rand(g, (batch, a_rows, lda), device=dev)[:, :, :K]
+        W = _rand(g, (N, K), scale=1 / math.sqrt(K), device=dev) if shared_w else _rand(g, (batch, N, K), scale=1 / math.sqrt(K), device=dev)
+    else:
+        A = _rand(g, (a_rows, lda), device=dev)[:, :K]
+        W = _rand(g, (taps, N, K), scale=1 / math.sqrt(K * taps), device=dev)
+    odt = F32 if out_fp32 else BF
+    oshape = (batch, M, n_out) if batch > 1 else (M, n_out)
+    out_h = torch.zeros(oshape, dtype=odt, device=dev)
+    out_e = torch.zeros(oshape, dtype=odt, device=dev)
+    if bias:
+        kw["bias"] = _rand(g, (N,), F32, 0.5, dev)
+    if add:
+        rpg = max(1, M // 6)
+        ngroups = (M + rpg - 1) // rpg
+        kw.update(add=_rand(g, (ngroups, N + 24), F32, 0.5, dev), add_rpg=rpg, add_ld=N + 24)
+    if res >= 1:
+        kw.update(res1=_rand(g, (M, n_out), device=dev), c_res1=0.75)
+    if res >= 2:
+        kw.update(res2=_rand(g, (M, n_out), device=dev), c_res2=-0.5)
+    kw["c_acc"] = 0.6 if res else 1.0
+    if coef:
+        rpg = max(1, M // 5)
+        kw.update(coef=_rand(g, ((M + rpg - 1) // rpg, 3), F32, 1.0, dev), coef_rpg=rpg)
+    base = dict(A=A, W=W, M=M, N=N, K=K, mode=mode, geglu=geglu, batch=batch, **kw)
+    hip.gemm(GemmCall(out=out_h, **base))
+    emu.gemm(GemmCall(out=out_e, **base))
+    return compare(out_h, out_e)
+
+
+def case_groupnorm(hip, emu, dev, *, n_img, S, C1, C2=0, imgs_per_stat=1, eps=1e-5, silu=True, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x1 = (_rand(g, (n_img * S, C1), F32, 1.0, dev) + 0.5).to(BF)
+    x2 = (_rand(g, (n_img * S, C2), F32, 2.0, dev) - 0.3).to(BF) if C2 else None
+    C = C1 + C2
+    gamma, beta = _rand(g, (C,), F32, 0.3, dev) + 1.0, _rand(g, (C,), F32, 0.3, dev)
+    o_h = hip.groupnorm(x1, x2, gamma, beta, n_img, S, eps=eps, silu=silu, imgs_per_stat=imgs_per_stat)
+    o_e = emu.groupnorm(x1, x2, gamma, beta, n_img, S, eps=eps, silu=silu, imgs_per_stat=imgs_per_stat)
+    return compare(o_h, o_e)
+
+
+def case_layernorm(hip, emu, dev, *, M, C, add=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (_rand(g, (M, C), F32, 1.5, dev) + 0.2).to(BF)
+    gamma, beta = _rand(g, (C,), F32, 0.3, dev) + 1.0, _rand(g, (C,), F32, 0.3, dev)
+    kw = {}
+    xs_h = xs_e = None
+    if add:
+        rpg = max(1, M // 4)
+        kw = dict(add=_rand(g, ((M + rpg - 1) // rpg, C), F32, 0.5, dev), add_rpg=rpg, add_ld=C)
+        xs_h, xs_e = torch.zeros_like(x), torch.zeros_like(x)
+    o_h, o_e = torch.zeros_like(x), torch.zeros_like(x)
+    hip.layernorm(x, gamma, beta, o_h, 1e-5, xsum_out=xs_h, **kw)
+    emu.layernorm(x, gamma, beta, o_e, 1e-5, xsum_out=xs_e, **kw)
+    rel, cos = compare(o_h, o_e)
+    if add:
+        r2, c2 = compare(xs_h, xs_e)
+        rel, cos = max(rel, r2), min(cos, c2)
+    return rel, cos
+
+
+def case_attn_spatial(hip, emu, dev, *, n_img, S, heads, seed=0, spike=False):
+    g = torch.Generator().manual_seed(seed)
+    C = heads * 64
+    qk = _rand(g, (n_img * S, 2 * C), device=dev)
+    if spike:  # force large running-max jumps late in the key sequence (online-softmax rescale path)
+        qk[S // 2 + 3, C:] *= 6.0
+        qk[S - 5, C:] *= 9.0
+    vT = _rand(g, (n_img, C, S), device=dev)
+    o_h = torch.zeros((n_img * S, C), dtype=BF, device=dev)
+    o_e = torch.zeros_like(o_h)
+    hip.attn_spatial(qk[:, :C], qk[:, C:], vT, o_h, n_img, S, heads, 0.125)
+    emu.attn_spatial(qk[:, :C], qk[:, C:], vT, o_e, n_img, S, heads, 0.125)
+    return compare(o_h, o_e)
+
+
+def case_attn_temporal(hip, emu, dev, *, B, Tq, Tk, S, heads, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    C = heads * 64
+    q = _rand(g, (B, Tq, S, C), device=dev)
+    kv = _rand(g, (B, Tk, S, 2 * C), device=dev)
+    o_h = torch.zeros((B, Tq, S, C), dtype=BF, device=dev)
+    o_e = torch.zeros_like(o_h)
+    hip.attn_temporal(q, kv[..., :C], kv[..., C:], o_h, heads, 0.125)
+    emu.attn_temporal(q, kv[..., :C], kv[..., C:], o_e, heads, 0.125)
+    return compare(o_h, o_e)
+
+
+def case_softmax(hip, emu, dev, *, rows, L, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = _rand(g, (rows, L), F32, 3.0, dev)
+    o_h = torch.zeros((rows, L), dtype=BF, device=dev)
+    o_e = torch.zeros_like(o_h)
+    hip.softmax_rows(x, o_h)
+    emu.softmax_rows(x, o_e)
+    return compare(o_h, o_e)
+
+
+def case_elementwise(hip, emu, dev, seed=0):
+    """All small sampler / boundary kernels; returns the worst (rel, cos) over them, plus per-op detail."""
+    g = torch.Generator().manual_seed(seed)
+    res = {}
+    n, T, H, W = 12, 6, 8, 8
+    t = _rand(g, (n,), F32, 2.0, dev).abs() + 0.1
+    res["timestep_embedding"] = compare(hip.timestep_embedding(t, 64), emu.timestep_embedding(t, 64))
+    res["timestep_embedding_odd"] = compare(hip.timestep_embedding(t, 65, 100.0), emu.timestep_embedding(t, 65, 100.0))
+    a, b = _rand(g, (n, 96), F32, 1.0, dev), _rand(g, (n, 96), F32, 1.0, dev)
+    res["silu_add"] = compare(hip.silu_add(a, b), emu.silu_add(a, b))
+    res["silu"] = compare(hip.silu_add(a), emu.silu_add(a))
+    sig = t * 10
+    for i, (h_, e_) in enumerate(zip(hip.edm_scalings(sig), emu.edm_scalings(sig))):
+        res[f"edm_scalings{i}"] = compare(h_, e_)
+    x = _rand(g, (n, 4, H, W), F32, 1.0, dev)
+    cond = _rand(g, (n, 4, H, W), F32, 1.0, dev)
+    sc = _rand(g, (n,), F32, 1.0, dev)
+    res["pack_input"] = compare(hip.pack_input(x, sc, cond, 8), emu.pack_input(x, sc, cond, 8))
+    res["pack_input_pad"] = compare(hip.pack_input(x, None, None, 8), emu.pack_input(x, None, None, 8))
+    net = _rand(g, (n * H * W, 4), F32, 1.0, dev)
+    res["denoise_combine"] = compare(hip.denoise_combine(net, x, sc, t), emu.denoise_combine(net, x, sc, t))
+    scale = _rand(g, (T,), F32, 1.0, dev) + 3
+    res["cfg_combine"] = compare(hip.cfg_combine(x, scale, T), emu.cfg_combine(x, scale, T))
+    res["euler_step"] = compare(hip.euler_step(x, cond, sig, sig * 0.5), emu.euler_step(x, cond, sig, sig * 0.5))
+    res["axpb"] = compare(hip.axpb_f32(x, 1.5, -0.25), emu.axpb_f32(x, 1.5, -0.25))
+    alpha = torch.sigmoid(_rand(g, (5,), F32, 1.0, dev))
+    kind = torch.tensor([0, 1, 0, 1, 1], dtype=torch.int32, device=dev)
+    ioi = torch.zeros(n, dtype=F32, device=dev)
+    ioi[3] = 1.0
+    res["blend_coefs"] = compare(hip.blend_coefs(alpha, kind, ioi, n), emu.blend_coefs(alpha, kind, ioi, n))
+    res["blend_coefs_noioi"] = compare(hip.blend_coefs(alpha, kind, None, n), emu.blend_coefs(alpha, kind, None, n))
+    res["nchw_to_nhwc"] = compare(hip.nchw_to_nhwc_bf16(x, 0.5, 8), emu.nchw_to_nhwc_bf16(x, 0.5, 8))
+    xt = _rand(g, (2 * T * H * W, 4), F32, 1.0, dev)
+    w3, b3 = _rand(g, (3, 3, 3), F32, 0.5, dev), _rand(g, (3,), F32, 0.5, dev)
+    res["tmix_small"] = compare(hip.tmix_small(xt, w3, b3, 2, T, H * W, 3, 0, T - 1), emu.tmix_small(xt, w3, b3, 2, T, H * W, 3, 0, T - 1))
+    src = _rand(g, (40, 48), device=dev)
+    d_h = torch.zeros((40, 64), dtype=BF, device=dev)
+    d_e = torch.zeros_like(d_h)
+    hip.copy2d_bf16(src[:, 8:40], d_h[:, 16:48])
+    emu.copy2d_bf16(src[:, 8:40], d_e[:, 16:48])
+    res["copy2d"] = compare(d_h, d_e)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# The case table.  (name, fn, kwargs, tol).  Shapes marked [V3D] are the exact shapes of the V3D_512 census
+# (SURVEY.md Appendix A.2); the others are ragged / edge shapes (M, N, K tails, odd T, uneven frame shards).
+def all_cases(full: bool = True):
+    C = []
+    L, C3, CT = GEMM_LINEAR, GEMM_CONV3X3, GEMM_CONVT3
+    C += [
+        ("gemm_linear_tiny", case_gemm, dict(M=64, N=64, K=64), TOL_BF16),
+        ("gemm_linear_ragged", case_gemm, dict(M=200, N=72, K=40, add=True, res=2), TOL_BF16),
+        ("gemm_linear_n4_fp32", case_gemm, dict(M=300, N=4, K=320, out_fp32=True), TOL_BF16),
+        ("gemm_linear_n3_ldo3", case_gemm, dict(M=130, N=3, K=128, out_fp32=True, bias=True), TOL_BF16),
+        ("gemm_linear_coef", case_gemm, dict(M=384, N=320, K=320, res=2, coef=True), TOL_BF16),
+        ("gemm_linear_lda_strided", case_gemm, dict(M=256, N=128, K=64, lda_pad=128), TOL_BF16),
+        ("gemm_geglu", case_gemm, dict(M=192, N=256, K=320, geglu=True, res=1), TOL_BF16),
+        ("gemm_geglu_n64tile", case_gemm, dict(M=192, N=320, K=64, geglu=True), TOL_BF16),
+        ("gemm_batched_sharedW", case_gemm, dict(M=96, N=192, K=128, batch=3, bias=False), TOL_BF16),
+        ("gemm_batched_perbatchW", case_gemm, dict(M=128, N=128, K=512, batch=2, bias=False, shared_w=False, out_fp32=True), TOL_BF16),
+        ("conv3x3_small", case_gemm, dict(M=0, N=64, K=32, mode=C3, conv=(2, 8, 8, 1, 1)), TOL_BF16),
+        ("conv3x3_odd_hw", case_gemm, dict(M=0, N=40, K=24, mode=C3, conv=(3, 7, 5, 1, 1), add=True, res=1), TOL_BF16),
+        ("conv3x3_stride2", case_gemm, dict(M=0, N=64, K=64, mode=C3, conv=(2, 16, 16, 2, 1)), TOL_BF16),
+        ("conv3x3_up2", case_gemm, dict(M=0, N=64, K=64, mode=C3, conv=(2, 8, 8, 1, 2)), TOL_BF16),
+        ("conv3x3_k8", case_gemm, dict(M=0, N=320, K=8, mode=C3, conv=(2, 16, 16, 1, 1)), TOL_BF16),
+        ("convt3_small", case_gemm, dict(M=0, N=64, K=64, mode=CT, convt=(2, 5, 16, 0, 0, 4), res=1, coef=True), TOL_BF16),
+        ("convt3_T1", case_gemm, dict(M=0, N=64, K=64, mode=CT, convt=(3, 1, 16, 0, 0, 0)), TOL_BF16),
+        ("convt3_halo_shard", case_gemm, dict(M=0, N=64, K=64, mode=CT, convt=(1, 3, 16, 1, -1, 3)), TOL_BF16),
+        ("convt3_halo_leftedge", case_gemm, dict(M=0, N=64, K=64, mode=CT, convt=(1, 2, 16, 1, 0, 2)), TOL_BF16),
+        ("gn2d_320", case_groupnorm, dict(n_img=4, S=256, C1=320), TOL_BF16),
+        ("gn2d_concat_1920", case_groupnorm, dict(n_img=2, S=64, C1=1280, C2=640), TOL_BF16),
+        ("gn2d_concat_2560", case_groupnorm, dict(n_img=2, S=64, C1=1280, C2=1280, silu=False, eps=1e-6), TOL_BF16),
+        ("gn3d_T3", case_groupnorm, dict(n_img=6, S=64, C1=320, imgs_per_stat=3), TOL_BF16),
+        ("gn_vae_128", case_groupnorm, dict(n_img=2, S=1024, C1=128, eps=1e-6), TOL_BF16),
+        ("gn_S1", case_groupnorm, dict(n_img=3, S=1, C1=64), TOL_BF16),
+        ("ln_320", case_layernorm, dict(M=257, C=320), TOL_BF16),
+        ("ln_1280_add", case_layernorm, dict(M=96, C=1280, add=True), TOL_BF16),
+        ("ln_64", case_layernorm, dict(M=33, C=64, add=True), TOL_BF16),
+        ("attn_spatial_S64", case_attn_spatial, dict(n_img=3, S=64, heads=2), TOL_BF16),
+        ("attn_spatial_S256", case_attn_spatial, dict(n_img=2, S=256, heads=3), TOL_BF16),
+        ("attn_spatial_S144_ragged", case_attn_spatial, dict(n_img=2, S=144, heads=1), TOL_BF16),
+        ("attn_spatial_S16", case_attn_spatial, dict(n_img=2, S=16, heads=1), TOL_BF16),
+        ("attn_spatial_spike", case_attn_spatial, dict(n_img=1, S=512, heads=1, spike=True), TOL_BF16),
+        ("attn_temporal_T18", case_attn_temporal, dict(B=2, Tq=18, Tk=18, S=16, heads=5), TOL_BF16),
+        ("attn_temporal_T3", case_attn_temporal, dict(B=2, Tq=3, Tk=3, S=4, heads=1), TOL_BF16),
+        ("attn_temporal_shard_2of18", case_attn_temporal, dict(B=2, Tq=2, Tk=18, S=8, heads=2), TOL_BF16),
+        ("attn_temporal_T25", case_attn_temporal, dict(B=1, Tq=25, Tk=25, S=8, heads=1), TOL_BF16),
+        ("softmax_4096", case_softmax, dict(rows=64, L=4096), TOL_BF16),
+        ("softmax_64", case_softmax, dict(rows=7, L=64), TOL_BF16),
+    ]
+    if full:
+        C += [
+            # [V3D] level-0 shapes at batch 36 are large; keep parity cases to a few images of the same geometry
+            ("gemm_V3D_ff1_L0", case_gemm, dict(M=4 * 4096, N=2560, K=320, geglu=True), TOL_BF16),
+            ("gemm_V3D_ff2_L0", case_gemm, dict(M=4 * 4096, N=320, K=1280, res=2, coef=True), TOL_BF16),
+            ("gemm_V3D_qk_L2", case_gemm, dict(M=36 * 256, N=2560, K=1280, bias=False), TOL_BF16),
+            ("gemm_V3D_emb_M36", case_gemm, dict(M=36, N=1280, K=1280, out_fp32=True), TOL_BF16),
+            ("conv3x3_V3D_L0", case_gemm, dict(M=0, N=320, K=320, mode=C3, conv=(4, 64, 64, 1, 1), add=True), TOL_BF16),
+            ("conv3x3_V3D_L3_2560", case_gemm, dict(M=0, N=1280, K=2560, mode=C3, conv=(36, 8, 8, 1, 1), res=1), TOL_BF16),
+            ("conv3x3_V3D_down", case_gemm, dict(M=0, N=320, K=320, mode=C3, conv=(4, 64, 64, 2, 1)), TOL_BF16),
+            ("conv3x3_V3D_up", case_gemm, dict(M=0, N=640, K=640, mode=C3, conv=(4, 32, 32, 1, 2)), TOL_BF16),
+            ("conv3x3_V3D_out4", case_gemm, dict(M=0, N=4, K=320, mode=C3, conv=(4, 64, 64, 1, 1), out_fp32=True), TOL_BF16),
+            ("convt3_V3D_L1", case_gemm, dict(M=0, N=640, K=640, mode=CT, convt=(2, 18, 1024, 0, 0, 17), res=1, coef=True, add=True), TOL_BF16),
+            ("gn2d_V3D_960_64x64", case_groupnorm, dict(n_img=4, S=4096, C1=640, C2=320), TOL_BF16),
+            ("gn3d_V3D_L2", case_groupnorm, dict(n_img=36, S=256, C1=1280, imgs_per_stat=18), TOL_BF16),
+            ("ln_V3D_L0", case_layernorm, dict(M=2 * 4096, C=320, add=True), TOL_BF16),
+            ("attn_spatial_V3D_L0", case_attn_spatial, dict(n_img=2, S=4096, heads=5), TOL_BF16),
+            ("attn_spatial_V3D_L1", case_attn_spatial, dict(n_img=4, S=1024, heads=10), TOL_BF16),
+            ("attn_temporal_V3D_L1", case_attn_temporal, dict(B=2, Tq=18, Tk=18, S=1024, heads=10), TOL_BF16),
+            ("vae_attn_scores", case_gemm, dict(M=1024, N=1024, K=512, batch=2, bias=False, shared_w=False, out_fp32=True), TOL_BF16),
+        ]
+    return C
+
+
+def run_case(hip, emu, dev, name, fn, kwargs, tol):
+    rel, cos = fn(hip, emu, dev, **kwargs)
+    ok = (rel <= tol) and (cos >= 0.999)
+    return rel, cos, ok

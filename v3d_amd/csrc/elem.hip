@@ -1,0 +1,256 @@
+// Small elementwise / layout kernels of the sampler loop and the network boundary (gfx950).
+#include "common.h"
+
+namespace {
+
+inline unsigned nblocks(long long n, int per_block = 256, long long cap = 1 << 20) {
+    long long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, long long n, int dim, float neg_log_period) {
+    const int half = dim / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n * dim; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dim;
+        const int c = (int)(i - r * dim);
+        float v = 0.f;
+        if (c < 2 * half) {
+            const int f = c < half ? c : c - half;
+            const float freq = expf(neg_log_period * (float)f / (float)half);
+            const float a = t[r] * freq;
+            v = c < half ? cosf(a) : sinf(a);
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+__global__ void silu_add_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = a[i];
+        if (b) v += b[i];
+        out[i] = f2bf(v / (1.0f + expf(-v)));
+    }
+}
+
+__global__ void edm_scalings_kernel(const float* __restrict__ sigma, float* c_skip, float* c_out, float* c_in, float* c_noise, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = sigma[i];
+    const float d = s * s + 1.0f;
+    c_skip[i] = 1.0f / d;
+    c_out[i] = -s / sqrtf(d);
+    c_in[i] = 1.0f / sqrtf(d);
+    c_noise[i] = 0.25f * logf(s);
+}
+
+// out[n][s][c] (bf16, ld = Cpad) from NCHW fp32 sources
+__global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ scale, long long C1,
+                                  const float* __restrict__ cond, long long C2, bf16_t* __restrict__ out, long long n,
+                                  long long S, long long Cpad) {
+    const long long total = n * S * Cpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long c = i % Cpad;
+        const long long rs = i / Cpad;
+        const long long s = rs % S, img = rs / S;
+        float v = 0.f;
+        if (c < C1) {
+            v = x[(img * C1 + c) * S + s];
+            if (scale) v *= scale[img];
+        } else if (c < C1 + C2) {
+            v = cond[(img * C2 + (c - C1)) * S + s];
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+__global__ void denoise_combine_kernel(const float* __restrict__ net, long long ldn, const float* __restrict__ x,
+                                       const float* __restrict__ c_out, const float* __restrict__ c_skip,
+                                       float* __restrict__ out, long long n, long long C, long long S) {
+    const long long total = n * C * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long s = i % S;
+        const long long ic = i / S;
+        const long long c = ic % C, img = ic / C;
+        out[i] = net[(img * S + s) * ldn + c] * c_out[img] + x[i] * c_skip[img];
+    }
+}
+
+__global__ void cfg_combine_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ out,
+                                   long long n, long long T, long long chw) {
+    const long long total = n * chw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / chw;
+        const float u = x[i], c = x[total + i];
+        out[i] = u + scale[img % T] * (c - u);
+    }
+}
+
+__global__ void euler_step_kernel(const float* __restrict__ x, const float* __restrict__ den, const float* __restrict__ sigma,
+                                  const float* __restrict__ next_sigma, float* __restrict__ out, long long n, long long chw) {
+    const long long total = n * chw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / chw;
+        const float sg = sigma[img];
+        const float d = (x[i] - den[i]) / sg;
+        out[i] = x[i] + (next_sigma[img] - sg) * d;
+    }
+}
+
+__global__ void axpb_kernel(const float* __restrict__ x, float a, float b, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = a * x[i] + b;
+}
+
+__global__ void blend_coefs_kernel(const float* __restrict__ alpha, const int* __restrict__ kind, const float* __restrict__ ioi,
+                                   float* __restrict__ out, long long n_mixers, long long n_img) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_mixers * n_img) return;
+    const long long mx = i / n_img, g = i - mx * n_img;
+    float a = alpha[mx];
+    if (ioi && ioi[g] != 0.f) a = 1.0f;
+    float* o = out + i * 3;
+    if (kind[mx] == 0) {
+        o[0] = 1.0f - a; o[1] = 1.0f; o[2] = 0.f;
+    } else {
+        o[0] = 1.0f - a; o[1] = 1.0f - a; o[2] = a;
+    }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float scale, bf16_t* __restrict__ out, long long n, long long C,
+                                    long long S, long long Cpad) {
+    const long long total = n * S * Cpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long c = i % Cpad;
+        const long long rs = i / Cpad;
+        const long long s = rs % S, img = rs / S;
+        out[i] = f2bf(c < C ? x[(img * C + c) * S + s] * scale : 0.f);
+    }
+}
+
+// Conv3d (3,1,1) over frames on <= 4 channels; one thread per (frame, s)
+__global__ void tmix_small_kernel(const float* __restrict__ x, long long ld, const float* __restrict__ w, const float* __restrict__ b,
+                                  float* __restrict__ out, long long B, int T, long long S, int Cc, int tmin, int tmax) {
+    const long long total = B * T * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long s = i % S;
+        const long long f = i / S;
+        const int t = (int)(f % T);
+        float acc[4];
+#pragma unroll
+        for (int co = 0; co < 4; ++co) acc[co] = co < Cc ? b[co] : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int tt = t + dt - 1;
+            if (tt < tmin || tt > tmax) continue;
+            const float* xp = x + ((f + dt - 1) * S + s) * ld;
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                if (ci < Cc) {
+                    const float xv = xp[ci];
+#pragma unroll
+                    for (int co = 0; co < 4; ++co)
+                        if (co < Cc) acc[co] += w[(co * Cc + ci) * 3 + dt] * xv;
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 4; ++co)
+            if (co < Cc) out[(f * Cc + co) * S + s] = acc[co];
+    }
+}
+
+__global__ void copy2d_kernel(const bf16_t* __restrict__ src, long long lds, bf16_t* __restrict__ dst, long long ldd, long long rows, long long VC) {
+    const long long total = rows * VC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / VC, v = i - r * VC;
+        *reinterpret_cast<uint4*>(dst + r * ldd + v * 8) = *reinterpret_cast<const uint4*>(src + r * lds + v * 8);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int v3d_timestep_embedding(const float* t, void* out_bf16, int64_t n, int32_t dim, float max_period, v3d_stream_t stream) {
+    V3D_REQUIRE(t && out_bf16 && n > 0 && dim >= 2, "v3d_timestep_embedding: bad args");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(nblocks(n * dim)), dim3(256), 0, ST, t, (bf16_t*)out_bf16, (long long)n, dim, -logf(max_period));
+    return v3d_check_launch("v3d_timestep_embedding");
+}
+
+extern "C" int v3d_silu_add(const float* in, const float* in2, void* out_bf16, int64_t n, v3d_stream_t stream) {
+    V3D_REQUIRE(in && out_bf16 && n > 0, "v3d_silu_add: bad args");
+    hipLaunchKernelGGL(silu_add_kernel, dim3(nblocks(n)), dim3(256), 0, ST, in, in2, (bf16_t*)out_bf16, (long long)n);
+    return v3d_check_launch("v3d_silu_add");
+}
+
+extern "C" int v3d_edm_scalings(const float* sigma, float* c_skip, float* c_out, float* c_in, float* c_noise, int64_t n, v3d_stream_t stream) {
+    V3D_REQUIRE(sigma && c_skip && c_out && c_in && c_noise && n > 0, "v3d_edm_scalings: bad args");
+    hipLaunchKernelGGL(edm_scalings_kernel, dim3(nblocks(n)), dim3(256), 0, ST, sigma, c_skip, c_out, c_in, c_noise, (long long)n);
+    return v3d_check_launch("v3d_edm_scalings");
+}
+
+extern "C" int v3d_pack_input(const float* x, const float* scale, int64_t C1, const float* cond, int64_t C2, void* out_bf16,
+                              int64_t n, int64_t S, int64_t Cpad, v3d_stream_t stream) {
+    V3D_REQUIRE(x && out_bf16 && n > 0 && S > 0 && C1 > 0 && Cpad >= C1 + C2, "v3d_pack_input: bad args");
+    V3D_REQUIRE((C2 == 0) == (cond == nullptr), "v3d_pack_input: cond/C2 mismatch");
+    hipLaunchKernelGGL(pack_input_kernel, dim3(nblocks(n * S * Cpad)), dim3(256), 0, ST, x, scale, (long long)C1, cond, (long long)C2,
+                       (bf16_t*)out_bf16, (long long)n, (long long)S, (long long)Cpad);
+    return v3d_check_launch("v3d_pack_input");
+}
+
+extern "C" int v3d_denoise_combine(const float* net, int64_t ldn, const float* x, const float* c_out, const float* c_skip,
+                                   float* out, int64_t n, int64_t C, int64_t S, v3d_stream_t stream) {
+    V3D_REQUIRE(net && x && c_out && c_skip && out && n > 0 && C > 0 && S > 0 && ldn >= C, "v3d_denoise_combine: bad args");
+    hipLaunchKernelGGL(denoise_combine_kernel, dim3(nblocks(n * C * S)), dim3(256), 0, ST, net, (long long)ldn, x, c_out, c_skip, out,
+                       (long long)n, (long long)C, (long long)S);
+    return v3d_check_launch("v3d_denoise_combine");
+}
+
+extern "C" int v3d_cfg_combine(const float* x, const float* scale, float* out, int64_t n, int64_t T, int64_t chw, v3d_stream_t stream) {
+    V3D_REQUIRE(x && scale && out && n > 0 && T > 0 && chw > 0, "v3d_cfg_combine: bad args");
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(nblocks(n * chw)), dim3(256), 0, ST, x, scale, out, (long long)n, (long long)T, (long long)chw);
+    return v3d_check_launch("v3d_cfg_combine");
+}
+
+extern "C" int v3d_euler_step(const float* x, const float* den, const float* sigma, const float* next_sigma, float* out,
+                              int64_t n, int64_t chw, v3d_stream_t stream) {
+    V3D_REQUIRE(x && den && sigma && next_sigma && out && n > 0 && chw > 0, "v3d_euler_step: bad args");
+    hipLaunchKernelGGL(euler_step_kernel, dim3(nblocks(n * chw)), dim3(256), 0, ST, x, den, sigma, next_sigma, out, (long long)n, (long long)chw);
+    return v3d_check_launch("v3d_euler_step");
+}
+
+extern "C" int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream) {
+    V3D_REQUIRE(x && out && n > 0, "v3d_axpb_f32: bad args");
+    hipLaunchKernelGGL(axpb_kernel, dim3(nblocks(n)), dim3(256), 0, ST, x, a, b, out, (long long)n);
+    return v3d_check_launch("v3d_axpb_f32");
+}
+
+extern "C" int v3d_blend_coefs(const float* alpha, const int32_t* kind, const float* ioi, float* out, int64_t n_mixers, int64_t n_img, v3d_stream_t stream) {
+    V3D_REQUIRE(alpha && kind && out && n_mixers > 0 && n_img > 0, "v3d_blend_coefs: bad args");
+    hipLaunchKernelGGL(blend_coefs_kernel, dim3(nblocks(n_mixers * n_img)), dim3(256), 0, ST, alpha, kind, ioi, out, (long long)n_mixers, (long long)n_img);
+    return v3d_check_launch("v3d_blend_coefs");
+}
+
+extern "C" int v3d_nchw_to_nhwc_bf16(const float* x, float scale, void* out_bf16, int64_t n, int64_t C, int64_t S, int64_t Cpad, v3d_stream_t stream) {
+    V3D_REQUIRE(x && out_bf16 && n > 0 && C > 0 && S > 0 && Cpad >= C, "v3d_nchw_to_nhwc_bf16: bad args");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks(n * S * Cpad)), dim3(256), 0, ST, x, scale, (bf16_t*)out_bf16, (long long)n, (long long)C,
+                       (long long)S, (long long)Cpad);
+    return v3d_check_launch("v3d_nchw_to_nhwc_bf16");
+}
+
+extern "C" int v3d_tmix_small(const float* x, int64_t ld, const float* w, const float* b, float* out, int64_t B, int32_t T,
+                              int64_t S, int32_t Cc, int32_t tmin, int32_t tmax, v3d_stream_t stream) {
+    V3D_REQUIRE(x && w && b && out && B > 0 && T > 0 && S > 0, "v3d_tmix_small: bad args");
+    V3D_REQUIRE(Cc >= 1 && Cc <= 4 && ld >= Cc, "v3d_tmix_small: Cc must be in [1,4]");
+    hipLaunchKernelGGL(tmix_small_kernel, dim3(nblocks(B * T * S)), dim3(256), 0, ST, x, (long long)ld, w, b, out, (long long)B, T, (long long)S, Cc, tmin, tmax);
+    return v3d_check_launch("v3d_tmix_small");
+}
+
+extern "C" int v3d_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t C, v3d_stream_t stream) {
+    V3D_REQUIRE(src && dst && rows > 0 && C > 0 && C % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, "v3d_copy2d_bf16: bad args");
+    V3D_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "v3d_copy2d_bf16: misaligned");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(nblocks(rows * (C / 8))), dim3(256), 0, ST, (const bf16_t*)src, (long long)lds, (bf16_t*)dst, (long long)ldd,
+                       (long long)rows, (long long)(C / 8));
+    return v3d_check_launch("v3d_copy2d_bf16");
+}

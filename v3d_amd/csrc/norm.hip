@@ -1,0 +1,335 @@
+// GroupNorm (stats / apply), LayerNorm and row softmax for channels-last bf16 activations (gfx950).
+// All of these are HBM-bound: every access is a 16-byte (8 x bf16) per-lane vector, coalesced along channels.
+#include "common.h"
+
+namespace {
+
+constexpr int NVMAX = 2;       // vector columns per thread -> supports C <= 2*256*8 = 4096
+constexpr int CMAX = 4096;
+
+struct GNGeom {
+    int VC;    // 16-B vectors per row
+    int TPR;   // threads per row
+    int RPP;   // rows per pass of a 256-thread block
+    int NV;    // vector columns per thread
+};
+
+__host__ __device__ inline GNGeom gn_geom(long long C) {
+    GNGeom g;
+    g.VC = (int)(C / 8);
+    g.TPR = g.VC < 256 ? g.VC : 256;
+    g.RPP = 256 / g.TPR;
+    g.NV = (g.VC + g.TPR - 1) / g.TPR;
+    return g;
+}
+
+__device__ __forceinline__ uint4 load_vec2(const bf16_t* x1, long long C1, const bf16_t* x2, long long C2, long long row, int c) {
+    if (c < C1) return *reinterpret_cast<const uint4*>(x1 + row * C1 + c);
+    return *reinterpret_cast<const uint4*>(x2 + row * C2 + (c - C1));
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    f[0] = bflo(u.x); f[1] = bfhi(u.x); f[2] = bflo(u.y); f[3] = bfhi(u.y);
+    f[4] = bflo(u.z); f[5] = bfhi(u.z); f[6] = bflo(u.w); f[7] = bfhi(u.w);
+}
+
+// grid (chunks, n_img); block 256.  Each block reduces rows [chunk*rpb, (chunk+1)*rpb) of one image.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x1, long long C1,
+                                                       const bf16_t* __restrict__ x2, long long C2,
+                                                       float* __restrict__ stats, long long S, int groups,
+                                                       long long imgs_per_stat, long long rpb) {
+    __shared__ float sh_s[CMAX];
+    __shared__ float sh_q[CMAX];
+    const long long C = C1 + C2;
+    const GNGeom g = gn_geom(C);
+    const int tid = threadIdx.x;
+    const long long img = blockIdx.y;
+    const long long r_begin = (long long)blockIdx.x * rpb;
+    long long r_end = r_begin + rpb;
+    if (r_end > S) r_end = S;
+
+    for (int c = tid; c < C; c += 256) {
+        sh_s[c] = 0.f;
+        sh_q[c] = 0.f;
+    }
+    __syncthreads();
+
+    const int trow = tid / g.TPR;
+    const int tcol = tid - trow * g.TPR;
+    float s[NVMAX][8], q[NVMAX][8];
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[j][e] = q[j][e] = 0.f;
+
+    if (trow < g.RPP) {
+        for (long long r = r_begin + trow; r < r_end; r += g.RPP) {
+            const long long row = img * S + r;
+#pragma unroll
+            for (int j = 0; j < NVMAX; ++j) {
+                const int v = tcol + j * g.TPR;
+                if (j < g.NV && v < g.VC) {
+                    float f[8];
+                    unpack8(load_vec2(x1, C1, x2, C2, row, v * 8), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s[j][e] += f[e];
+                        q[j][e] += f[e] * f[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) {
+            const int v = tcol + j * g.TPR;
+            if (j < g.NV && v < g.VC) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    atomicAdd(&sh_s[v * 8 + e], s[j][e]);
+                    atomicAdd(&sh_q[v * 8 + e], q[j][e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int cpg = (int)(C / groups);
+    if (tid < groups) {
+        float a = 0.f, b = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            a += sh_s[c];
+            b += sh_q[c];
+        }
+        float* dst = stats + ((img / imgs_per_stat) * groups + tid) * 2;
+        atomicAdd(dst, a);
+        atomicAdd(dst + 1, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x1, long long C1,
+                                                       const bf16_t* __restrict__ x2, long long C2,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ out, long long S, int groups,
+                                                       long long imgs_per_stat, float inv_count, float eps, int silu,
+                                                       long long rpb) {
+    const long long C = C1 + C2;
+    const GNGeom g = gn_geom(C);
+    const int tid = threadIdx.x;
+    const long long img = blockIdx.y;
+    const long long r_begin = (long long)blockIdx.x * rpb;
+    long long r_end = r_begin + rpb;
+    if (r_end > S) r_end = S;
+    const int trow = tid / g.TPR;
+    const int tcol = tid - trow * g.TPR;
+    if (trow >= g.RPP) return;
+    const int cpg = (int)(C / groups);
+    const float* st = stats + (img / imgs_per_stat) * groups * 2;
+
+    float sc[NVMAX][8], sf[NVMAX][8];
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j) {
+        const int v = tcol + j * g.TPR;
+        if (j < g.NV && v < g.VC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = v * 8 + e;
+                const int grp = c / cpg;
+                const float mean = st[grp * 2] * inv_count;
+                float var = st[grp * 2 + 1] * inv_count - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                const float rstd = rsqrtf(var + eps);
+                const float ga = gamma[c] * rstd;
+                sc[j][e] = ga;
+                sf[j][e] = beta[c] - mean * ga;
+            }
+        }
+    }
+    for (long long r = r_begin + trow; r < r_end; r += g.RPP) {
+        const long long row = img * S + r;
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) {
+            const int v = tcol + j * g.TPR;
+            if (j < g.NV && v < g.VC) {
+                float f[8];
+                unpack8(load_vec2(x1, C1, x2, C2, row, v * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = f[e] * sc[j][e] + sf[j][e];
+                    f[e] = silu ? silu_f(y) : y;
+                }
+                uint4 o = make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+                *reinterpret_cast<uint4*>(out + row * C + v * 8) = o;
+            }
+        }
+    }
+}
+
+// One wave per row, row kept in registers (C <= 64*8*LNV = 2048).
+constexpr int LNV = 4;
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
+                                                        long long add_rpg, long long add_ld, bf16_t* __restrict__ xsum,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ out, long long M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int VC = C / 8;
+    float f[LNV][8];
+    const float* av = add ? add + (row / add_rpg) * add_ld : nullptr;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNV; ++j) {
+        const int v = lane + 64 * j;
+        if (v < VC) {
+            unpack8(*reinterpret_cast<const uint4*>(x + row * C + v * 8), f[j]);
+            if (av) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[j][e] += av[v * 8 + e];
+                if (xsum) {
+                    uint4 o = make_uint4(pack2bf(f[j][0], f[j][1]), pack2bf(f[j][2], f[j][3]), pack2bf(f[j][4], f[j][5]), pack2bf(f[j][6], f[j][7]));
+                    *reinterpret_cast<uint4*>(xsum + row * C + v * 8) = o;
+                    unpack8(o, f[j]);  // normalise exactly what was stored
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += f[j][e];
+        }
+    }
+    sum = wave_sum(sum);
+    const float mean = sum / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNV; ++j) {
+        const int v = lane + 64 * j;
+        if (v < VC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = f[j][e] - mean;
+                var += d * d;
+            }
+        }
+    }
+    var = wave_sum(var) / (float)C;
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < LNV; ++j) {
+        const int v = lane + 64 * j;
+        if (v < VC) {
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (f[j][e] - mean) * rstd * gamma[v * 8 + e] + beta[v * 8 + e];
+            uint4 o = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
+            *reinterpret_cast<uint4*>(out + row * C + v * 8) = o;
+        }
+    }
+}
+
+// one block per row; L % 4 == 0
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long L) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const float* p = in + row * L;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (long long i = tid * 4; i < L; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (long long i = tid * 4; i < L; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        sum += __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx);
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / sum;
+    bf16_t* o = out + row * L;
+    for (long long i = tid * 4; i < L; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        const uint2 w = make_uint2(pack2bf(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv),
+                                   pack2bf(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv));
+        *reinterpret_cast<uint2*>(o + i) = w;
+    }
+}
+
+inline void gn_grid(long long n_img, long long S, const GNGeom& g, long long& chunks, long long& rpb) {
+    long long want = 4096 / (n_img > 0 ? n_img : 1);
+    if (want < 1) want = 1;
+    long long maxchunks = (S + g.RPP - 1) / g.RPP;
+    chunks = want < maxchunks ? want : maxchunks;
+    if (chunks > 65535) chunks = 65535;
+    rpb = (S + chunks - 1) / chunks;
+    chunks = (S + rpb - 1) / rpb;
+}
+
+int gn_check(const char* who, const void* x1, long long C1, const void* x2, long long C2, long long n_img, long long S, int groups) {
+    V3D_REQUIRE(x1 != nullptr && C1 > 0, "%s: null x1", who);
+    V3D_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0, "%s: channel counts must be multiples of 8 (%lld,%lld)", who, C1, C2);
+    V3D_REQUIRE((C2 == 0) == (x2 == nullptr), "%s: x2/C2 mismatch", who);
+    V3D_REQUIRE(groups > 0 && groups <= 256 && (C1 + C2) % groups == 0, "%s: bad groups", who);
+    V3D_REQUIRE(C1 + C2 <= CMAX, "%s: C > %d unsupported", who, CMAX);
+    V3D_REQUIRE(n_img > 0 && n_img <= 65535 && S > 0, "%s: bad n_img/S", who);
+    return V3D_OK;
+}
+
+}  // namespace
+
+extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats,
+                                   int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, v3d_stream_t stream) {
+    int rc = gn_check("v3d_groupnorm_stats", x1, C1, x2, C2, n_img, S, groups);
+    if (rc) return rc;
+    V3D_REQUIRE(stats != nullptr && imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_stats: bad stats/imgs_per_stat");
+    const GNGeom g = gn_geom(C1 + C2);
+    long long chunks, rpb;
+    gn_grid(n_img, S, g, chunks, rpb);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)chunks, (unsigned)n_img), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x1, (long long)C1, (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups,
+                       (long long)imgs_per_stat, rpb);
+    return v3d_check_launch("v3d_groupnorm_stats");
+}
+
+extern "C" int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* stats,
+                                   const float* gamma, const float* beta, void* out, int64_t n_img, int64_t S,
+                                   int32_t groups, int64_t imgs_per_stat, double count, float eps, int32_t silu,
+                                   v3d_stream_t stream) {
+    int rc = gn_check("v3d_groupnorm_apply", x1, C1, x2, C2, n_img, S, groups);
+    if (rc) return rc;
+    V3D_REQUIRE(stats && gamma && beta && out, "v3d_groupnorm_apply: null pointer");
+    V3D_REQUIRE(imgs_per_stat > 0 && n_img % imgs_per_stat == 0 && count > 0, "v3d_groupnorm_apply: bad imgs_per_stat/count");
+    const GNGeom g = gn_geom(C1 + C2);
+    long long chunks, rpb;
+    gn_grid(n_img, S, g, chunks, rpb);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)chunks, (unsigned)n_img), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x1, (long long)C1, (const bf16_t*)x2, (long long)C2, stats, gamma, beta,
+                       (bf16_t*)out, (long long)S, groups, (long long)imgs_per_stat, (float)(1.0 / count), eps, silu, rpb);
+    return v3d_check_launch("v3d_groupnorm_apply");
+}
+
+extern "C" int v3d_layernorm(const void* x, const float* add, int64_t add_rpg, int64_t add_ld, void* xsum_out,
+                             const float* gamma, const float* beta, void* out, int64_t M, int64_t C, float eps,
+                             v3d_stream_t stream) {
+    V3D_REQUIRE(x && gamma && beta && out, "v3d_layernorm: null pointer");
+    V3D_REQUIRE(C % 8 == 0 && C > 0 && C <= 64 * 8 * LNV, "v3d_layernorm: C=%lld unsupported (multiple of 8, <= %d)", (long long)C, 64 * 8 * LNV);
+    V3D_REQUIRE(M > 0, "v3d_layernorm: bad M");
+    V3D_REQUIRE(!add || add_rpg > 0, "v3d_layernorm: add_rpg must be > 0");
+    V3D_REQUIRE(!xsum_out || add, "v3d_layernorm: xsum_out requires add");
+    const long long blocks = (M + 3) / 4;
+    V3D_REQUIRE(blocks < (1ll << 31), "v3d_layernorm: M too large");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, add,
+                       (long long)add_rpg, (long long)add_ld, (bf16_t*)xsum_out, gamma, beta, (bf16_t*)out, (long long)M, (int)C, eps);
+    return v3d_check_launch("v3d_layernorm");
+}
+
+extern "C" int v3d_softmax_rows(const float* in, void* out, int64_t rows, int64_t L, v3d_stream_t stream) {
+    V3D_REQUIRE(in && out && rows > 0 && L > 0 && L % 4 == 0, "v3d_softmax_rows: bad args");
+    V3D_REQUIRE(rows < (1ll << 31), "v3d_softmax_rows: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long long)L);
+    return v3d_check_launch("v3d_softmax_rows");
+}

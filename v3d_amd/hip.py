@@ -1,0 +1,339 @@
+"""ctypes binding of libv3d_hip.so (include/v3d_hip.h) — the product operator backend.
+
+Tensors are only used as device-memory handles here (`data_ptr()`), torch provides the stream.  Everything
+fails loudly: a missing library, a missing symbol, a non-GPU tensor or a non-zero return code raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from .ops import GemmCall, OpsBase
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libv3d_hip.so")
+
+ABI_VERSION = 1
+
+c_i64, c_i32, c_f32, c_f64, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_void_p
+
+
+class _GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", c_vp), ("W", c_vp), ("out", c_vp), ("bias", c_vp), ("add", c_vp), ("res1", c_vp), ("res2", c_vp),
+        ("coef", c_vp),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("lda", c_i64), ("ldo", c_i64), ("ldr1", c_i64), ("ldr2", c_i64),
+        ("a_rows", c_i64), ("a_row0", c_i64),
+        ("add_rpg", c_i64), ("add_ld", c_i64), ("coef_rpg", c_i64),
+        ("c_acc", c_f32), ("c_res1", c_f32), ("c_res2", c_f32),
+        ("mode", c_i32), ("geglu", c_i32), ("out_fp32", c_i32),
+        ("Hin", c_i32), ("Win", c_i32), ("Hout", c_i32), ("Wout", c_i32), ("stride", c_i32), ("up", c_i32),
+        ("T", c_i32), ("tmin", c_i32), ("tmax", c_i32),
+        ("S", c_i64),
+        ("batch", c_i32),
+        ("sA", c_i64), ("sW", c_i64), ("sO", c_i64),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/v3d_hip.h
+SIGNATURES = {
+    "v3d_abi_version": (c_i32, []),
+    "v3d_last_error": (C.c_char_p, []),
+    "v3d_device_info": (c_i32, [c_vp]),
+    "v3d_gemm": (c_i32, [C.POINTER(_GemmArgs), c_vp]),
+    "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp]),
+    "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i64,
+                                    c_f64, c_f32, c_i32, c_vp]),
+    "v3d_layernorm": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp]),
+    "v3d_attn_spatial": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
+    "v3d_attn_temporal": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64,
+                                  c_i64, c_i64, c_i32, c_i32, c_i64, c_i32, c_f32, c_vp]),
+    "v3d_softmax_rows": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "v3d_timestep_embedding": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
+    "v3d_silu_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "v3d_edm_scalings": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "v3d_pack_input": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "v3d_denoise_combine": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "v3d_cfg_combine": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "v3d_euler_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "v3d_axpb_f32": (c_i32, [c_vp, c_f32, c_f32, c_vp, c_i64, c_vp]),
+    "v3d_blend_coefs": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "v3d_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
+    "v3d_tmix_small": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "v3d_copy2d_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the C-ABI library and bind every declared symbol (no GPU needed for this step)."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python -m v3d_amd.build`). There is no CPU fallback for the V3D hot path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.v3d_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libv3d_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild the extension")
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipOps(OpsBase):
+    name = "hip"
+
+    def __init__(self, device: Optional[torch.device] = None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("v3d_amd: no HIP device visible (torch.cuda.is_available() is False); the V3D hot path "
+                               "has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        info = (c_i32 * 4)()
+        self._check(self.lib.v3d_device_info(C.cast(info, c_vp)), "v3d_device_info")
+        self.cu_count, self.lds_bytes, self.wave_size, self.arch = info[0], info[1], info[2], info[3]
+        if self.wave_size != 64:
+            raise RuntimeError(f"v3d_amd kernels are wave64 gfx950 code; device reports wave size {self.wave_size}")
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.v3d_last_error()
+            raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    @staticmethod
+    def _req(t: torch.Tensor, dtype, what: str, inner_contig: bool = True):
+        if t.device.type != "cuda":
+            raise RuntimeError(f"{what}: tensor is on {t.device}, HIP ops need device memory")
+        if t.dtype != dtype:
+            raise RuntimeError(f"{what}: dtype {t.dtype} != {dtype}")
+        if inner_contig and t.dim() > 0 and t.stride(-1) != 1 and t.shape[-1] != 1:
+            raise RuntimeError(f"{what}: inner stride must be 1")
+        return t
+
+    @staticmethod
+    def _req_c(t: torch.Tensor, dtype, what: str):
+        HipOps._req(t, dtype, what)
+        if not t.is_contiguous():
+            raise RuntimeError(f"{what}: tensor must be contiguous")
+        return t
+
+    # ---- primitives -------------------------------------------------------------------------------
+    def gemm(self, g: GemmCall):
+        bf, f32 = torch.bfloat16, torch.float32
+        a = _GemmArgs()
+        self._req(g.A, bf, "gemm.A")
+        self._req(g.W, bf, "gemm.W")
+        if g.W.stride(-2) != g.K:
+            raise RuntimeError("gemm.W rows must be densely packed (stride == K)")
+        out_fp32 = g.out.dtype == f32
+        self._req(g.out, f32 if out_fp32 else bf, "gemm.out")
+        a.A, a.W, a.out = g.A.data_ptr(), g.W.data_ptr(), g.out.data_ptr()
+        a.bias = _ptr(None if g.bias is None else self._req_c(g.bias, f32, "gemm.bias"))
+        a.add = _ptr(None if g.add is None else self._req(g.add, f32, "gemm.add"))
+        a.res1 = _ptr(None if g.res1 is None else self._req(g.res1, bf, "gemm.res1"))
+        a.res2 = _ptr(None if g.res2 is None else self._req(g.res2, bf, "gemm.res2"))
+        a.coef = _ptr(None if g.coef is None else self._req_c(g.coef, f32, "gemm.coef"))
+        a.M, a.N, a.K = g.M, g.N, g.K
+        a.lda = g.A.stride(-2) if g.A.dim() >= 2 else g.K
+        a.ldo = g.out.stride(-2)
+        a.ldr1 = 0 if g.res1 is None else g.res1.stride(-2)
+        a.ldr2 = 0 if g.res2 is None else g.res2.stride(-2)
+        a.a_rows = g.a_rows if g.a_rows else g.A.shape[-2]
+        a.a_row0 = g.a_row0
+        a.add_rpg, a.add_ld, a.coef_rpg = g.add_rpg, g.add_ld, g.coef_rpg
+        a.c_acc, a.c_res1, a.c_res2 = g.c_acc, g.c_res1, g.c_res2
+        a.mode, a.geglu, a.out_fp32 = g.mode, int(g.geglu), int(out_fp32)
+        a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up = g.Hin, g.Win, g.Hout, g.Wout, g.stride, g.up
+        a.T, a.tmin, a.tmax, a.S = g.T, g.tmin, g.tmax, g.S
+        a.batch = g.batch
+        if g.batch > 1:
+            if g.mode != 0:
+                raise RuntimeError("gemm: batching is only defined for LINEAR mode")
+            a.sA = g.A.stride(0) if g.A.dim() == 3 else 0
+            a.sW = g.W.stride(0) if g.W.dim() == 3 else 0
+            a.sO = g.out.stride(0) if g.out.dim() == 3 else 0
+            if g.out.dim() != 3:
+                raise RuntimeError("gemm: batched out must be 3-D")
+        self._check(self.lib.v3d_gemm(C.byref(a), self._stream()), "v3d_gemm")
+
+    def groupnorm_stats(self, x1, x2, stats, n_img, S, groups, imgs_per_stat):
+        bf = torch.bfloat16
+        self._req_c(x1, bf, "gn.x1")
+        if x2 is not None:
+            self._req_c(x2, bf, "gn.x2")
+        self._req_c(stats, torch.float32, "gn.stats")
+        self._check(self.lib.v3d_groupnorm_stats(x1.data_ptr(), x1.shape[-1], _ptr(x2), 0 if x2 is None else x2.shape[-1],
+                                                 stats.data_ptr(), n_img, S, groups, imgs_per_stat, self._stream()),
+                    "v3d_groupnorm_stats")
+
+    def groupnorm_apply(self, x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu):
+        bf, f32 = torch.bfloat16, torch.float32
+        self._req_c(x1, bf, "gn.x1")
+        if x2 is not None:
+            self._req_c(x2, bf, "gn.x2")
+        self._req_c(stats, f32, "gn.stats"); self._req_c(gamma, f32, "gn.gamma"); self._req_c(beta, f32, "gn.beta")
+        self._req_c(out, bf, "gn.out")
+        self._check(self.lib.v3d_groupnorm_apply(x1.data_ptr(), x1.shape[-1], _ptr(x2), 0 if x2 is None else x2.shape[-1],
+                                                 stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                                 n_img, S, groups, imgs_per_stat, float(count), float(eps), int(silu),
+                                                 self._stream()), "v3d_groupnorm_apply")
+
+    def layernorm(self, x, gamma, beta, out, eps, add=None, add_rpg=0, add_ld=0, xsum_out=None):
+        bf, f32 = torch.bfloat16, torch.float32
+        self._req_c(x, bf, "ln.x"); self._req_c(out, bf, "ln.out")
+        self._req_c(gamma, f32, "ln.gamma"); self._req_c(beta, f32, "ln.beta")
+        if add is not None:
+            self._req(add, f32, "ln.add")
+        if xsum_out is not None:
+            self._req_c(xsum_out, bf, "ln.xsum_out")
+        M, Cc = x.numel() // x.shape[-1], x.shape[-1]
+        self._check(self.lib.v3d_layernorm(x.data_ptr(), _ptr(add), add_rpg, add_ld, _ptr(xsum_out), gamma.data_ptr(),
+                                           beta.data_ptr(), out.data_ptr(), M, Cc, float(eps), self._stream()), "v3d_layernorm")
+
+    def attn_spatial(self, q, k, vT, out, n_img, S, heads, scale):
+        bf = torch.bfloat16
+        self._req(q, bf, "attn.q"); self._req(k, bf, "attn.k"); self._req_c(vT, bf, "attn.vT"); self._req(out, bf, "attn.out")
+        self._check(self.lib.v3d_attn_spatial(q.data_ptr(), q.stride(-2), k.data_ptr(), k.stride(-2), vT.data_ptr(),
+                                              out.data_ptr(), out.stride(-2), n_img, S, heads, float(scale), self._stream()),
+                    "v3d_attn_spatial")
+
+    def attn_temporal(self, q, k, v, out, heads, scale):
+        """q/out: [B, Tq, S, C] views, k/v: [B, Tk, S, C] views (any strides with unit inner stride)."""
+        bf = torch.bfloat16
+        for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+            self._req(t, bf, f"tattn.{nm}")
+        B, Tq, S, _ = q.shape
+        Tk = k.shape[1]
+        assert k.stride()[:3] == v.stride()[:3], "k and v must share strides"
+        self._check(self.lib.v3d_attn_temporal(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+                                               k.data_ptr(), v.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+                                               out.data_ptr(), out.stride(0), out.stride(1), out.stride(2),
+                                               B, Tq, Tk, S, heads, float(scale), self._stream()), "v3d_attn_temporal")
+
+    def softmax_rows(self, inp, out):
+        self._req_c(inp, torch.float32, "softmax.in"); self._req_c(out, torch.bfloat16, "softmax.out")
+        L = inp.shape[-1]
+        self._check(self.lib.v3d_softmax_rows(inp.data_ptr(), out.data_ptr(), inp.numel() // L, L, self._stream()), "v3d_softmax_rows")
+
+    def timestep_embedding(self, t, dim, max_period=10000.0):
+        self._req_c(t, torch.float32, "temb.t")
+        out = self.empty((t.numel(), dim), torch.bfloat16, t.device)
+        self._check(self.lib.v3d_timestep_embedding(t.data_ptr(), out.data_ptr(), t.numel(), dim, float(max_period), self._stream()),
+                    "v3d_timestep_embedding")
+        return out
+
+    def silu_add(self, a, b=None):
+        self._req_c(a, torch.float32, "silu.a")
+        if b is not None:
+            self._req_c(b, torch.float32, "silu.b")
+        out = self.empty(a.shape, torch.bfloat16, a.device)
+        self._check(self.lib.v3d_silu_add(a.data_ptr(), _ptr(b), out.data_ptr(), a.numel(), self._stream()), "v3d_silu_add")
+        return out
+
+    def edm_scalings(self, sigma):
+        self._req_c(sigma, torch.float32, "edm.sigma")
+        outs = [torch.empty_like(sigma) for _ in range(4)]
+        self._check(self.lib.v3d_edm_scalings(sigma.data_ptr(), *[o.data_ptr() for o in outs], sigma.numel(), self._stream()),
+                    "v3d_edm_scalings")
+        return tuple(outs)
+
+    def pack_input(self, x, scale, cond, Cpad):
+        f32 = torch.float32
+        self._req_c(x, f32, "pack.x")
+        n, C1 = x.shape[0], x.shape[1]
+        S = x.numel() // (n * C1)
+        C2 = 0
+        if cond is not None:
+            self._req_c(cond, f32, "pack.cond")
+            C2 = cond.shape[1]
+        if scale is not None:
+            self._req_c(scale, f32, "pack.scale")
+        out = self.empty((n * S, Cpad), torch.bfloat16, x.device)
+        self._check(self.lib.v3d_pack_input(x.data_ptr(), _ptr(scale), C1, _ptr(cond), C2, out.data_ptr(), n, S, Cpad, self._stream()),
+                    "v3d_pack_input")
+        return out
+
+    def denoise_combine(self, net, x, c_out, c_skip):
+        f32 = torch.float32
+        self._req(net, f32, "dc.net"); self._req_c(x, f32, "dc.x"); self._req_c(c_out, f32, "dc.c_out"); self._req_c(c_skip, f32, "dc.c_skip")
+        n, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (n * Cc)
+        out = torch.empty_like(x)
+        self._check(self.lib.v3d_denoise_combine(net.data_ptr(), net.stride(-2), x.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(),
+                                                 out.data_ptr(), n, Cc, S, self._stream()), "v3d_denoise_combine")
+        return out
+
+    def cfg_combine(self, x, scale, T):
+        f32 = torch.float32
+        self._req_c(x, f32, "cfg.x"); self._req_c(scale, f32, "cfg.scale")
+        n = x.shape[0] // 2
+        chw = x.numel() // x.shape[0]
+        out = torch.empty((n,) + tuple(x.shape[1:]), dtype=f32, device=x.device)
+        self._check(self.lib.v3d_cfg_combine(x.data_ptr(), scale.data_ptr(), out.data_ptr(), n, T, chw, self._stream()), "v3d_cfg_combine")
+        return out
+
+    def euler_step(self, x, den, sigma, next_sigma):
+        f32 = torch.float32
+        for t, nm in ((x, "x"), (den, "den"), (sigma, "sigma"), (next_sigma, "next")):
+            self._req_c(t, f32, f"euler.{nm}")
+        out = torch.empty_like(x)
+        n = x.shape[0]
+        self._check(self.lib.v3d_euler_step(x.data_ptr(), den.data_ptr(), sigma.data_ptr(), next_sigma.data_ptr(), out.data_ptr(),
+                                            n, x.numel() // n, self._stream()), "v3d_euler_step")
+        return out
+
+    def axpb_f32(self, x, a, b=0.0, out=None):
+        self._req_c(x, torch.float32, "axpb.x")
+        if out is None:
+            out = torch.empty_like(x)
+        self._check(self.lib.v3d_axpb_f32(x.data_ptr(), float(a), float(b), out.data_ptr(), x.numel(), self._stream()), "v3d_axpb_f32")
+        return out
+
+    def blend_coefs(self, alpha, kind, ioi, n_img):
+        self._req_c(alpha, torch.float32, "blend.alpha"); self._req_c(kind, torch.int32, "blend.kind")
+        if ioi is not None:
+            self._req_c(ioi, torch.float32, "blend.ioi")
+        nm = alpha.numel()
+        out = self.empty((nm, n_img, 3), torch.float32, alpha.device)
+        self._check(self.lib.v3d_blend_coefs(alpha.data_ptr(), kind.data_ptr(), _ptr(ioi), out.data_ptr(), nm, n_img, self._stream()),
+                    "v3d_blend_coefs")
+        return out
+
+    def nchw_to_nhwc_bf16(self, x, scale, Cpad):
+        self._req_c(x, torch.float32, "nchw.x")
+        n, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (n * Cc)
+        out = self.empty((n * S, Cpad), torch.bfloat16, x.device)
+        self._check(self.lib.v3d_nchw_to_nhwc_bf16(x.data_ptr(), float(scale), out.data_ptr(), n, Cc, S, Cpad, self._stream()),
+                    "v3d_nchw_to_nhwc_bf16")
+        return out
+
+    def tmix_small(self, x, w, b, B, T, S, Cc, tmin, tmax):
+        f32 = torch.float32
+        self._req(x, f32, "tmix.x"); self._req_c(w, f32, "tmix.w"); self._req_c(b, f32, "tmix.b")
+        out = self.empty((B * T, Cc, S), f32, x.device)
+        self._check(self.lib.v3d_tmix_small(x.data_ptr(), x.stride(-2), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, T, S, Cc,
+                                            tmin, tmax, self._stream()), "v3d_tmix_small")
+        return out
+
+    def copy2d_bf16(self, src, dst):
+        bf = torch.bfloat16
+        self._req(src, bf, "copy.src"); self._req(dst, bf, "copy.dst")
+        rows, Cc = src.shape
+        self._check(self.lib.v3d_copy2d_bf16(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), rows, Cc, self._stream()),
+                    "v3d_copy2d_bf16")
+        return dst

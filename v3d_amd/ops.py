@@ -1,0 +1,157 @@
+"""Operator interface of the V3D hot path.
+
+The engine (v3d_amd/engine/*) is written against the primitive operator set below, whose names and semantics
+are exactly the C ABI in include/v3d_hip.h.  The product backend is :class:`v3d_amd.hip.HipOps` (ctypes ->
+libv3d_hip.so, hand-written gfx950 kernels).  There is NO CPU/PyTorch fallback in the product: resolving the
+default backend without a usable HIP library raises.  Tests inject oracle/ops_emul.py (a torch restatement of
+each C-ABI op) through :func:`use_backend` to check the host logic and as the per-op checker on the GPU.
+"""
+from __future__ import annotations
+
+import contextlib
+import dataclasses
+from typing import Optional
+
+import torch
+
+GEMM_LINEAR, GEMM_CONV3X3, GEMM_CONVT3 = 0, 1, 2
+
+
+@dataclasses.dataclass
+class GemmCall:
+    """Mirror of `v3d_gemm_args` (include/v3d_hip.h) with tensors instead of raw pointers.
+
+    A: 2-D bf16 view [a_rows, >=K] with unit inner stride (row stride = lda).  W: bf16 [taps, N, K] contiguous
+    (batched: [batch, taps, N, K] with sW given).  out: 2-D view [M, N_out] (bf16 or fp32, row stride = ldo).
+    """
+    A: torch.Tensor
+    W: torch.Tensor
+    out: torch.Tensor
+    M: int
+    N: int
+    K: int
+    bias: Optional[torch.Tensor] = None
+    add: Optional[torch.Tensor] = None      # fp32, indexed [(m // add_rpg) * add_ld + n]
+    add_rpg: int = 0
+    add_ld: int = 0
+    res1: Optional[torch.Tensor] = None     # bf16 2-D views [M, N_out]
+    res2: Optional[torch.Tensor] = None
+    coef: Optional[torch.Tensor] = None     # fp32 [groups, 3]
+    coef_rpg: int = 0
+    c_acc: float = 1.0
+    c_res1: float = 1.0
+    c_res2: float = 1.0
+    mode: int = GEMM_LINEAR
+    geglu: bool = False
+    # conv3x3 geometry
+    Hin: int = 0
+    Win: int = 0
+    Hout: int = 0
+    Wout: int = 0
+    stride: int = 1
+    up: int = 1
+    # convt3 geometry
+    T: int = 0
+    S: int = 0
+    tmin: int = 0
+    tmax: int = 0
+    a_row0: int = 0
+    a_rows: int = 0          # 0 -> A.shape[-2]
+    batch: int = 1           # batched (LINEAR only): A / W / out may be 3-D [batch, rows, cols]; a 2-D operand is shared
+
+
+class OpsBase:
+    """Primitive op names == C-ABI entry points (without the v3d_ prefix).  Subclasses implement them."""
+
+    name = "base"
+
+    # ---- allocation -------------------------------------------------------------------------------
+    def empty(self, shape, dtype=torch.bfloat16, device=None):
+        return torch.empty(shape, dtype=dtype, device=device if device is not None else self.device)
+
+    def zeros(self, shape, dtype=torch.float32, device=None):
+        return torch.zeros(shape, dtype=dtype, device=device if device is not None else self.device)
+
+    # ---- composite helpers shared by every backend ------------------------------------------------
+    def linear(self, x2d, w, bias=None, *, out=None, out_dtype=torch.bfloat16, geglu=False, **epi):
+        """x2d [M, K] (row-strided ok) @ w[N, K]^T with the fused epilogue of v3d_gemm."""
+        M, K = x2d.shape
+        N = w.shape[-2]
+        n_out = N // 2 if geglu else N
+        if out is None:
+            out = self.empty((M, n_out), out_dtype, x2d.device)
+        self.gemm(GemmCall(A=x2d, W=w, out=out, M=M, N=N, K=K, bias=bias, geglu=geglu, **epi))
+        return out
+
+    def conv3x3(self, x, w, bias, n_img, Hin, Win, *, stride=1, up=1, out=None, out_dtype=torch.bfloat16, **epi):
+        """x [n_img*Hin*Win, Cin] channels-last, w [9, Cout, Cin] -> [n_img*Hout*Wout, Cout]."""
+        Hl, Wl = Hin * up, Win * up
+        Hout, Wout = (Hl + 2 - 3) // stride + 1, (Wl + 2 - 3) // stride + 1
+        K = x.shape[-1]
+        N = w.shape[-2]
+        M = n_img * Hout * Wout
+        if out is None:
+            out = self.empty((M, N), out_dtype, x.device)
+        self.gemm(GemmCall(A=x, W=w, out=out, M=M, N=N, K=K, bias=bias, mode=GEMM_CONV3X3, Hin=Hin, Win=Win,
+                           Hout=Hout, Wout=Wout, stride=stride, up=up, **epi))
+        return out
+
+    def convt3(self, x, w, bias, T, S, *, tmin=0, tmax=None, a_row0=0, M=None, out=None, out_dtype=torch.bfloat16, **epi):
+        """Temporal 3-tap conv over frames: x [(b t) * S (+halo), C], w [3, Cout, Cin]."""
+        K = x.shape[-1]
+        N = w.shape[-2]
+        if M is None:
+            M = x.shape[0]
+        if tmax is None:
+            tmax = T - 1
+        if out is None:
+            out = self.empty((M, N), out_dtype, x.device)
+        self.gemm(GemmCall(A=x, W=w, out=out, M=M, N=N, K=K, bias=bias, mode=GEMM_CONVT3, T=T, S=S, tmin=tmin,
+                           tmax=tmax, a_row0=a_row0, **epi))
+        return out
+
+    def groupnorm(self, x1, x2, gamma, beta, n_img, S, *, eps, silu, imgs_per_stat=1, groups=32, stats_hook=None,
+                  count_imgs=None):
+        """GroupNorm(+SiLU) over channels-last x1 (and optional channel-concatenated x2).
+
+        stats_hook(stats) lets the frame-sharded runtime all-reduce (sum, sumsq) between the two kernels;
+        count_imgs = number of images (global) contributing to one statistics group.
+        """
+        C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+        stats = self.zeros((n_img // imgs_per_stat, groups, 2), torch.float32, x1.device)
+        self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
+        if stats_hook is not None:
+            stats = stats_hook(stats)
+        if count_imgs is None:
+            count_imgs = imgs_per_stat
+        count = float(count_imgs) * S * (C // groups)
+        out = self.empty((n_img * S, C), torch.bfloat16, x1.device)
+        self.groupnorm_apply(x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu)
+        return out
+
+
+_ACTIVE: Optional[OpsBase] = None
+_DEFAULT: Optional[OpsBase] = None
+
+
+def get_ops() -> OpsBase:
+    """Active operator backend.  Default = HIP kernels; raises if libv3d_hip.so / a GPU is unavailable."""
+    global _DEFAULT
+    if _ACTIVE is not None:
+        return _ACTIVE
+    if _DEFAULT is None:
+        from .hip import HipOps  # raises RuntimeError loudly when the extension cannot be used
+        _DEFAULT = HipOps()
+    return _DEFAULT
+
+
+@contextlib.contextmanager
+def use_backend(ops: OpsBase):
+    """Test hook: temporarily route the engine through another implementation of the op set."""
+    global _ACTIVE
+    prev = _ACTIVE
+    _ACTIVE = ops
+    try:
+        yield ops
+    finally:
+        _ACTIVE = prev
