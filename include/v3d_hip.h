@@ -75,7 +75,7 @@ typedef struct v3d_gemm_args {
     const void* res2;   /* bf16 [M][ldr2] or NULL */
     const float* coef;  /* [groups][3] or NULL */
     int64_t M, N, K;    /* N = rows of W per tap (2*N_out when geglu); K = contraction per tap, K % 8 == 0 */
-    int64_t lda, ldo, ldr1, ldr2;
+    int64_t lda, ldw, ldo, ldr1, ldr2; /* row strides (elements): A, W (0 -> K; lets a K-slice of a wider matrix be used), out, res1, res2 */
     int64_t a_rows;     /* rows of A addressable behind the pointer (hardware bounds check; < 4 GiB total) */
     int64_t a_row0;     /* row offset added to every source row (CONVT3 halo frames in front of frame 0), >= 0 */
     int64_t add_rpg, add_ld; /* rows per add group, stride (floats) between groups' vectors */
@@ -90,6 +90,8 @@ typedef struct v3d_gemm_args {
 } v3d_gemm_args;
 
 int v3d_gemm(const v3d_gemm_args* args, v3d_stream_t stream);
+/* sizeof(v3d_gemm_args) as compiled into the library: lets a foreign-language binding verify its struct mirror */
+int v3d_sizeof_gemm_args(void);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (32 groups) over channels-last activations, optionally over two channel-concatenated sources

@@ -15,29 +15,39 @@ import torch.nn.functional as F
 from v3d_amd.ops import GEMM_CONV3X3, GEMM_CONVT3, GEMM_LINEAR, GemmCall, OpsBase
 
 
+def _flat_from(t: torch.Tensor) -> torch.Tensor:
+    """1-D view of the storage starting at t's first element (C pointer semantics for strided `add` tables)."""
+    off = t.storage_offset()
+    total = t.untyped_storage().nbytes() // t.element_size()
+    return t.as_strided((total - off,), (1,), off)
+
+
 class EmulOps(OpsBase):
     name = "emul"
 
-    def __init__(self, device="cpu"):
+    def __init__(self, device="cpu", exact: bool = False):
+        """exact=True keeps activations / packed weights in fp32 (no bf16 rounding points): the engine's wiring can then be
+        checked against the fp32 oracle to ~1e-5, separating host-logic errors from precision."""
         self.device = torch.device(device)
+        self.act_dtype = torch.float32 if exact else torch.bfloat16
 
     # ---- v3d_gemm ---------------------------------------------------------------------------------
     def _gemm_acc(self, g: GemmCall, A, W):
         K, N, M = g.K, g.N, g.M
         if g.mode == GEMM_LINEAR:
-            return A[:M, :K].float() @ W.reshape(N, K).float().t()
+            return A[:M, :K].float() @ W.float().reshape(N, K).t()
         if g.mode == GEMM_CONV3X3:
             n_img = M // (g.Hout * g.Wout)
             x = A[: n_img * g.Hin * g.Win, :K].float().reshape(n_img, g.Hin, g.Win, K).permute(0, 3, 1, 2)
             if g.up == 2:
                 x = F.interpolate(x, scale_factor=2, mode="nearest")
-            w = W.reshape(3, 3, N, K).permute(2, 3, 0, 1).float()
+            w = W.float().reshape(3, 3, N, K).permute(2, 3, 0, 1)
             y = F.conv2d(x, w, stride=g.stride, padding=1)
             assert y.shape[2] == g.Hout and y.shape[3] == g.Wout, (y.shape, g.Hout, g.Wout)
             return y.permute(0, 2, 3, 1).reshape(M, N)
         if g.mode == GEMM_CONVT3:
             Af = A[:, :K].float()
-            w = W.reshape(3, N, K).float()
+            w = W.float().reshape(3, N, K)
             m = torch.arange(M, device=A.device)
             t = (m // g.S) % g.T
             acc = torch.zeros(M, N, dtype=torch.float32, device=A.device)
@@ -63,7 +73,7 @@ class EmulOps(OpsBase):
             if g.add is not None:
                 rows = torch.arange(M, device=v.device) // g.add_rpg
                 idx = rows[:, None] * g.add_ld + torch.arange(N, device=v.device)[None, :]
-                v = v + g.add.reshape(-1)[idx]
+                v = v + _flat_from(g.add)[idx]
             if g.geglu:
                 v4 = v.reshape(M, N // 32, 2, 16)
                 v = (v4[:, :, 0, :] * F.gelu(v4[:, :, 1, :])).reshape(M, N // 2)
@@ -111,9 +121,9 @@ class EmulOps(OpsBase):
         if add is not None:
             rows = torch.arange(M, device=x.device) // add_rpg
             idx = rows[:, None] * add_ld + torch.arange(C, device=x.device)[None, :]
-            xf = xf + add.reshape(-1)[idx]
+            xf = xf + _flat_from(add)[idx]
             if xsum_out is not None:
-                xs = xf.to(torch.bfloat16)
+                xs = xf.to(self.act_dtype)
                 xsum_out.reshape(-1, C).copy_(xs)
                 xf = xs.float()
         y = F.layer_norm(xf, (C,), gamma.float(), beta.float(), eps)
@@ -148,11 +158,11 @@ class EmulOps(OpsBase):
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
         if dim % 2:
             emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
-        return emb.to(torch.bfloat16)
+        return emb.to(self.act_dtype)
 
     def silu_add(self, a, b=None):
         v = a.float() if b is None else a.float() + b.float()
-        return (v * torch.sigmoid(v)).to(torch.bfloat16)
+        return (v * torch.sigmoid(v)).to(self.act_dtype)
 
     def edm_scalings(self, sigma):
         s = sigma.float()
@@ -171,7 +181,7 @@ class EmulOps(OpsBase):
         full = torch.cat(parts, dim=1)
         if full.shape[1] < Cpad:
             full = torch.cat([full, torch.zeros(n, Cpad - full.shape[1], S, device=x.device)], dim=1)
-        return full.permute(0, 2, 1).reshape(n * S, Cpad).to(torch.bfloat16)
+        return full.permute(0, 2, 1).reshape(n * S, Cpad).to(self.act_dtype)
 
     def denoise_combine(self, net, x, c_out, c_skip):
         n, C = x.shape[0], x.shape[1]

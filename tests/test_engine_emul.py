@@ -1,0 +1,74 @@
+"""Host-logic parity on CPU: the product engine (v3d_amd.engine / v3d_amd.sgm plugin classes) executed with the torch
+restatement of the C-ABI ops (oracle/ops_emul.py) injected, against the reference-generated fixtures.
+
+exact=True keeps fp32 storage: any residual error is a wiring error (tolerance 5e-5 relative).  exact=False reproduces
+the bf16 rounding points of the HIP kernels and is held to the bf16 tolerance of SURVEY.md §8d."""
+import pytest
+import torch
+
+from conftest import rel_cos
+from oracle.ops_emul import EmulOps
+from tiny import TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs
+from v3d_amd.ops import use_backend
+from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+
+torch.set_grad_enabled(False)
+MODES = [(True, 5e-5, 0.999999), (False, 4e-2, 0.999)]
+
+
+@pytest.mark.parametrize("exact,tol,cosmin", MODES)
+def test_unet(golden, exact, tol, cosmin):
+    p = TINY
+    T = p["T"]
+    _, _, _, x8, ts, ctx, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    with use_backend(EmulOps("cpu", exact=exact)):
+        net = build_unet()
+        ioi = torch.zeros(2, T)
+        out = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi)
+        assert out.shape == golden["unet_out"].shape
+        rel, cos = rel_cos(out, golden["unet_out"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)
+        ioi[1, 1] = 1.0
+        rel, cos = rel_cos(net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi), golden["unet_out_ioi"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)
+
+
+@pytest.mark.parametrize("exact,tol,cosmin", MODES)
+def test_decoder(golden, exact, tol, cosmin):
+    T = TINY["T"]
+    z = decoder_latents(T)
+    with use_backend(EmulOps("cpu", exact=exact)):
+        dec = build_decoder()
+        rel, cos = rel_cos(dec(z, timesteps=T), golden["dec_out"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)
+        rel, cos = rel_cos(dec(z[:1], timesteps=1), golden["dec_out_T1"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)
+
+
+@pytest.mark.parametrize("exact,tol,cosmin", MODES)
+def test_sampler_loop(golden, exact, tol, cosmin):
+    p = TINY
+    T = p["T"]
+    noise, c, uc, *_ = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    with use_backend(EmulOps("cpu", exact=exact)):
+        net = build_unet()
+        sampler, den, wr = build_sampler(T), build_denoiser(), OpenAIWrapper(net)
+        extra = {"image_only_indicator": torch.zeros(2, T), "num_video_frames": T}
+        x0 = noise.clone()
+        z = sampler(lambda i, s, cc: den(wr, i, s, cc, **extra), x0, cond=c, uc=uc)
+        rel, cos = rel_cos(z, golden["sample_z"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)
+        # prepare_sampling_loop scales the CALLER's noise tensor in place, like the reference (sampling.py:50)
+        assert torch.allclose(x0, noise * (1 + 700.0 ** 2) ** 0.5, rtol=1e-5)
+
+
+def test_packing_invalidation():
+    with use_backend(EmulOps("cpu", exact=True)):
+        net = build_unet()
+        p1 = net.packed()
+        assert net.packed() is p1
+        net.load_state_dict(net.state_dict())
+        assert net._packed is None
+        net.packed()
+        net.float()
+        assert net._packed is None

@@ -45,3 +45,5 @@ extern "C" int v3d_device_info(int32_t* out4) {
     out4[3] = arch;
     return V3D_OK;
 }
+
+extern "C" int v3d_sizeof_gemm_args(void) { return (int)sizeof(v3d_gemm_args); }

@@ -23,7 +23,7 @@ struct GP {
     const bf16_t* res2;
     const float* coef;
     long long M, N, K;
-    long long lda, ldo, ldr1, ldr2;
+    long long lda, ldw, ldo, ldr1, ldr2;
     long long add_rpg, add_ld, coef_rpg;
     float c_acc, c_res1, c_res2;
     int out_fp32;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GP p) {
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const long long n = n0 + r0 + 32 * i;
-            boff[i] = (n < p.N) ? (unsigned)((((long long)tap * p.N + n) * p.K + kc * 8) * 2) : kInvalid;
+            boff[i] = (n < p.N) ? (unsigned)((((long long)tap * p.N + n) * p.ldw + kc * 8) * 2) : kInvalid;
         }
     };
     set_tap(0);
@@ -354,13 +354,15 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     V3D_REQUIRE(mtiles * ntiles < (1ll << 31), "v3d_gemm: grid too large");
     const int taps = a->mode == V3D_GEMM_LINEAR ? 1 : (a->mode == V3D_GEMM_CONV3X3 ? 9 : 3);
     const unsigned long long a_bytes = (unsigned long long)a->a_rows * a->lda * 2ull;
-    const unsigned long long w_bytes = (unsigned long long)taps * a->N * a->K * 2ull;
+    const long long ldw = a->ldw ? a->ldw : a->K;
+    V3D_REQUIRE(ldw >= a->K && ldw % 8 == 0, "v3d_gemm: ldw must be >= K and a multiple of 8");
+    const unsigned long long w_bytes = ((unsigned long long)(taps * a->N - 1) * ldw + a->K) * 2ull;
     V3D_REQUIRE(a_bytes <= kMaxBufBytes && w_bytes <= kMaxBufBytes, "v3d_gemm: operand larger than 4 GiB - 256 B (A %llu B, W %llu B)", a_bytes, w_bytes);
     GP p;
     p.A = (const bf16_t*)a->A; p.W = (const bf16_t*)a->W; p.out = a->out;
     p.bias = a->bias; p.add = a->add; p.res1 = (const bf16_t*)a->res1; p.res2 = (const bf16_t*)a->res2; p.coef = a->coef;
     p.M = a->M; p.N = a->N; p.K = a->K;
-    p.lda = a->lda; p.ldo = a->ldo; p.ldr1 = a->ldr1; p.ldr2 = a->ldr2;
+    p.lda = a->lda; p.ldw = ldw; p.ldo = a->ldo; p.ldr1 = a->ldr1; p.ldr2 = a->ldr2;
     p.add_rpg = a->add_rpg; p.add_ld = a->add_ld; p.coef_rpg = a->coef_rpg;
     p.c_acc = a->c_acc; p.c_res1 = a->c_res1; p.c_res2 = a->c_res2;
     p.out_fp32 = a->out_fp32;

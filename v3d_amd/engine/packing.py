@@ -1,0 +1,365 @@
+"""Weight packing: nn.Module parameter owners (reference state-dict layout, fp32) -> kernel-ready device tensors.
+
+Layouts (include/v3d_hip.h): linear W [N][K] bf16; conv3x3 W [9][Cout][Cin] bf16 (tap = ky*3+kx); temporal conv
+W [3][Cout][Cin]; GEGLU projections with value/gate rows interleaved in groups of 16 so both halves of a pair land
+in the same lane of the MFMA epilogue; norm affine / biases fp32.  Weight-only algebra done here once:
+  * cross-attention to a single context token has softmax == 1, so attn2(x) = to_out(to_v(ctx)) for every query
+    (reference: attention.py:517-524,570-575): W_ov = to_out.W @ to_v.W is folded at pack
+    time and ALL blocks' W_ov are concatenated into one [sum C, context_dim] matrix (one GEMM per U-Net evaluation);
+  * every ResBlock's emb_layers Linear (spatial and temporal) is concatenated the same way (one GEMM per evaluation).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def _bf(t: torch.Tensor) -> torch.Tensor:
+    """Packed-weight storage: bf16 for the HIP kernels (the test emulator may ask for exact fp32)."""
+    from ..ops import get_ops
+    return t.detach().to(get_ops().act_dtype).contiguous()
+
+
+def _f(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(F32).contiguous()
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pack_linear(lin: nn.Linear, k_pad: int = 0):
+    w = lin.weight.detach()
+    if k_pad and w.shape[1] < k_pad:
+        w = torch.cat([w, w.new_zeros(w.shape[0], k_pad - w.shape[1])], dim=1)
+    return _bf(w), (None if lin.bias is None else _f(lin.bias))
+
+
+def pack_conv1x1(conv: nn.Module):
+    w = conv.weight.detach()
+    return _bf(w.reshape(w.shape[0], w.shape[1])), (None if conv.bias is None else _f(conv.bias))
+
+
+def pack_conv3x3(conv: nn.Conv2d):
+    w = conv.weight.detach()                      # [O, I, 3, 3]
+    O, I = w.shape[0], w.shape[1]
+    Ip = round_up(I, 8)
+    if Ip != I:
+        w = torch.cat([w, w.new_zeros(O, Ip - I, 3, 3)], dim=1)
+    return _bf(w.permute(2, 3, 0, 1).reshape(9, O, Ip)), (None if conv.bias is None else _f(conv.bias))
+
+
+def pack_convt3(conv: nn.Conv3d):
+    w = conv.weight.detach()                      # [O, I, 3, 1, 1]
+    O, I = w.shape[0], w.shape[1]
+    return _bf(w.reshape(O, I, 3).permute(2, 0, 1)), (None if conv.bias is None else _f(conv.bias))
+
+
+def pack_geglu(lin: nn.Linear):
+    """[2*inner, dim] (value rows then gate rows) -> rows interleaved as 16 value / 16 gate / 16 value / ..."""
+    w, b = lin.weight.detach(), lin.bias.detach()
+    inner = w.shape[0] // 2
+    assert inner % 16 == 0
+    wv, wg = w[:inner].reshape(inner // 16, 16, -1), w[inner:].reshape(inner // 16, 16, -1)
+    wp = torch.stack([wv, wg], dim=1).reshape(2 * inner, -1)
+    bp = torch.stack([b[:inner].reshape(-1, 16), b[inner:].reshape(-1, 16)], dim=1).reshape(2 * inner)
+    return _bf(wp), _f(bp)
+
+
+def pack_norm(n: nn.Module):
+    return _f(n.weight), _f(n.bias), float(n.eps)
+
+
+@dataclass
+class ResPack:
+    cin: int
+    cout: int
+    split: Optional[tuple]          # (C_h, C_skip) when the input is the never-materialised skip concat
+    gn1: tuple = None
+    w1: torch.Tensor = None
+    b1: torch.Tensor = None
+    gn2: tuple = None
+    w2: torch.Tensor = None
+    b2: torch.Tensor = None
+    skip_w: Optional[torch.Tensor] = None
+    skip_b: Optional[torch.Tensor] = None
+    emb_off: int = -1                # column of this block's spatial emb projection in emb_all (-1: none)
+    t_gn1: tuple = None
+    t_w1: torch.Tensor = None
+    t_b1: torch.Tensor = None
+    t_gn2: tuple = None
+    t_w2: torch.Tensor = None
+    t_b2: torch.Tensor = None
+    t_emb_off: int = -1
+    mixer: int = -1                  # row in the blend-coefficient table (U-Net)
+    alpha: float = 0.0               # host alpha (VAE blocks: scalar epilogue coefficient)
+
+
+@dataclass
+class FFPack:
+    w1: torch.Tensor
+    b1: torch.Tensor
+    w2: torch.Tensor
+    b2: torch.Tensor
+
+
+@dataclass
+class SVTPack:
+    C: int
+    heads: int
+    norm: tuple
+    proj_in: tuple
+    proj_out: tuple
+    s_norm1: tuple = None
+    s_wqk: torch.Tensor = None
+    s_wv: torch.Tensor = None
+    s_wo: tuple = None
+    s_ctx_off: int = 0
+    s_norm3: tuple = None
+    s_ff: FFPack = None
+    t_norm_in: tuple = None
+    t_ff_in: FFPack = None
+    t_norm1: tuple = None
+    t_wqkv: torch.Tensor = None
+    t_wo: tuple = None
+    t_ctx_off: int = 0
+    t_norm3: tuple = None
+    t_ff: FFPack = None
+    tpe: tuple = None                # time_pos_embed (w0, b0, w2, b2)
+    max_period: float = 10000.0
+    mixer: int = -1
+    tables: Dict = field(default_factory=dict)   # (B, tuple(frame ids)) -> [B*T, C] fp32 frame-position table
+
+
+@dataclass
+class UNetPack:
+    device: torch.device
+    in_channels: int
+    in_pad: int
+    model_channels: int
+    out_channels: int
+    context_dim: int
+    adm_in: Optional[int]
+    time_embed: tuple
+    label_emb: Optional[tuple]
+    conv_in: tuple
+    input_stages: List[list]
+    middle: list
+    output_stages: List[list]
+    out_norm: tuple
+    out_conv: tuple
+    emb_w: torch.Tensor
+    emb_b: torch.Tensor
+    ctx_w: torch.Tensor
+    ctx_b: torch.Tensor
+    mix_alpha: torch.Tensor
+    mix_kind: torch.Tensor
+    uses_ioi: bool
+
+
+def _pack_ff(ff) -> FFPack:
+    w1, b1 = pack_geglu(ff.net[0].proj)
+    w2, b2 = pack_linear(ff.net[2])
+    return FFPack(w1, b1, w2, b2)
+
+
+class _Collector:
+    """Accumulates the concatenated emb / ctx projection matrices and the mixer table while walking the net."""
+
+    def __init__(self):
+        self.emb_w, self.emb_b, self.emb_cols = [], [], 0
+        self.ctx_w, self.ctx_b, self.ctx_cols = [], [], 0
+        self.alphas, self.kinds = [], []
+
+    def add_emb(self, lin: nn.Linear) -> int:
+        off = self.emb_cols
+        self.emb_w.append(lin.weight.detach().float())
+        self.emb_b.append(lin.bias.detach().float())
+        self.emb_cols += lin.weight.shape[0]
+        return off
+
+    def add_ctx(self, attn) -> int:
+        off = self.ctx_cols
+        wo, wv = attn.to_out[0].weight.detach().float(), attn.to_v.weight.detach().float()
+        self.ctx_w.append(wo @ wv)
+        self.ctx_b.append(attn.to_out[0].bias.detach().float())
+        self.ctx_cols += wo.shape[0]
+        return off
+
+    def add_mixer(self, blender, kind: int) -> int:
+        self.alphas.append(blender.alpha_value())
+        self.kinds.append(kind)
+        return len(self.alphas) - 1
+
+
+def pack_resblock(rb, col: Optional[_Collector]) -> ResPack:
+    """U-Net VideoResBlock (2-D ResBlock + (3,1,1) time_stack + AlphaBlender)."""
+    p = ResPack(cin=rb.channels, cout=rb.out_channels, split=getattr(rb, "concat_split", None))
+    p.gn1 = pack_norm(rb.in_layers[0])
+    p.w1, p.b1 = pack_conv3x3(rb.in_layers[2])
+    p.gn2 = pack_norm(rb.out_layers[0])
+    p.w2, p.b2 = pack_conv3x3(rb.out_layers[3])
+    if not isinstance(rb.skip_connection, nn.Identity):
+        p.skip_w, p.skip_b = pack_conv1x1(rb.skip_connection)
+    if rb.emb_layers is not None:
+        p.emb_off = col.add_emb(rb.emb_layers[1])
+    ts = rb.time_stack
+    p.t_gn1 = pack_norm(ts.in_layers[0])
+    p.t_w1, p.t_b1 = pack_convt3(ts.in_layers[2])
+    p.t_gn2 = pack_norm(ts.out_layers[0])
+    p.t_w2, p.t_b2 = pack_convt3(ts.out_layers[3])
+    if ts.emb_layers is not None:
+        p.t_emb_off = col.add_emb(ts.emb_layers[1])
+    p.mixer = col.add_mixer(rb.time_mixer, 0)
+    return p
+
+
+def pack_svt(st, col: _Collector) -> SVTPack:
+    assert len(st.transformer_blocks) == 1 and len(st.time_stack) == 1, "transformer_depth > 1 is not used by V3D/SVD"
+    blk, tb = st.transformer_blocks[0], st.time_stack[0]
+    C = st.proj_in.weight.shape[0]
+    p = SVTPack(C=C, heads=st.n_heads, norm=pack_norm(st.norm), proj_in=pack_linear(st.proj_in), proj_out=pack_linear(st.proj_out))
+    assert st.d_head == 64, "attention kernels are specialised for d_head = 64"
+    p.s_norm1 = pack_norm(blk.norm1)
+    p.s_wqk = _bf(torch.cat([blk.attn1.to_q.weight.detach(), blk.attn1.to_k.weight.detach()], dim=0))
+    p.s_wv = _bf(blk.attn1.to_v.weight)
+    p.s_wo = pack_linear(blk.attn1.to_out[0])
+    p.s_ctx_off = col.add_ctx(blk.attn2)
+    p.s_norm3 = pack_norm(blk.norm3)
+    p.s_ff = _pack_ff(blk.ff)
+    assert tb.ff_in is not False and tb.is_res
+    p.t_norm_in = pack_norm(tb.norm_in)
+    p.t_ff_in = _pack_ff(tb.ff_in)
+    p.t_norm1 = pack_norm(tb.norm1)
+    p.t_wqkv = _bf(torch.cat([tb.attn1.to_q.weight.detach(), tb.attn1.to_k.weight.detach(), tb.attn1.to_v.weight.detach()], dim=0))
+    p.t_wo = pack_linear(tb.attn1.to_out[0])
+    assert tb.attn2 is not None, "disable_temporal_crossattention is not used by V3D/SVD"
+    p.t_ctx_off = col.add_ctx(tb.attn2)
+    p.t_norm3 = pack_norm(tb.norm3)
+    p.t_ff = _pack_ff(tb.ff)
+    p.tpe = pack_linear(st.time_pos_embed[0]) + pack_linear(st.time_pos_embed[2])
+    p.max_period = float(st.max_time_embed_period)
+    p.mixer = col.add_mixer(st.time_mixer, 1)
+    return p
+
+
+def pack_unet(net) -> UNetPack:
+    from ..sgm.modules.diffusionmodules.openaimodel import Downsample, Upsample
+    from ..sgm.modules.diffusionmodules.video_model import VideoResBlock
+    from ..sgm.modules.video_attention import SpatialVideoTransformer
+
+    col = _Collector()
+    dev = net.out[2].weight.device
+
+    def pack_stage(seq) -> list:
+        items = []
+        for m in seq:
+            if isinstance(m, VideoResBlock):
+                items.append(("res", pack_resblock(m, col)))
+            elif isinstance(m, SpatialVideoTransformer):
+                items.append(("svt", pack_svt(m, col)))
+            elif isinstance(m, Downsample):
+                items.append(("down", pack_conv3x3(m.op)))
+            elif isinstance(m, Upsample):
+                items.append(("up", pack_conv3x3(m.conv)))
+            elif isinstance(m, nn.Conv2d):
+                items.append(("conv_in", pack_conv3x3(m)))
+            else:
+                raise TypeError(f"unsupported U-Net stage member {type(m).__name__}")
+        return items
+
+    input_stages = [pack_stage(seq) for seq in net.input_blocks]
+    middle = pack_stage(net.middle_block)
+    output_stages = [pack_stage(seq) for seq in net.output_blocks]
+    conv_in = input_stages[0][0][1]
+    te = net.time_embed
+    time_embed = pack_linear(te[0]) + pack_linear(te[2])
+    label = None
+    adm_in = None
+    if net.num_classes == "sequential":
+        le = net.label_emb[0]
+        adm_in = le[0].weight.shape[1]
+        label = pack_linear(le[0], k_pad=round_up(adm_in, 8)) + pack_linear(le[2])
+    uses_ioi = net.merge_strategy == "learned_with_images"
+    return UNetPack(
+        device=dev, in_channels=net.in_channels, in_pad=round_up(net.in_channels, 8), model_channels=net.model_channels,
+        out_channels=net.out_channels, context_dim=net.context_dim, adm_in=adm_in, time_embed=time_embed, label_emb=label,
+        conv_in=conv_in, input_stages=input_stages, middle=middle, output_stages=output_stages,
+        out_norm=pack_norm(net.out[0]), out_conv=pack_conv3x3(net.out[2]),
+        emb_w=_bf(torch.cat(col.emb_w, 0)), emb_b=_f(torch.cat(col.emb_b, 0)),
+        ctx_w=_bf(torch.cat(col.ctx_w, 0)), ctx_b=_f(torch.cat(col.ctx_b, 0)),
+        mix_alpha=torch.tensor(col.alphas, dtype=F32, device=dev), mix_kind=torch.tensor(col.kinds, dtype=torch.int32, device=dev),
+        uses_ioi=uses_ioi)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# VAE decoder (reference: sgm/modules/diffusionmodules/model.py:604-748 Decoder; autoencoding/temporal_ae.py)
+# ---------------------------------------------------------------------------------------------------------
+@dataclass
+class AttnPack:
+    C: int
+    norm: tuple
+    wq: tuple
+    wk: tuple
+    wv: torch.Tensor
+    bv: torch.Tensor
+    proj: tuple
+
+
+@dataclass
+class VAEPack:
+    device: torch.device
+    z_channels: int
+    z_pad: int
+    conv_in: tuple
+    mid: list
+    up: List[dict]                   # index = i_level: {"blocks": [ResPack], "upsample": (w, b) | None}
+    norm_out: tuple
+    conv_out: tuple                  # conv3x3 128 -> out_ch (fp32 output, ld 4)
+    tmix_w: torch.Tensor             # [out_ch, out_ch, 3] fp32
+    tmix_b: torch.Tensor
+    out_ch: int
+
+
+def pack_vae_resblock(rb) -> ResPack:
+    p = ResPack(cin=rb.in_channels, cout=rb.out_channels, split=None)
+    p.gn1 = pack_norm(rb.norm1)
+    p.w1, p.b1 = pack_conv3x3(rb.conv1)
+    p.gn2 = pack_norm(rb.norm2)
+    p.w2, p.b2 = pack_conv3x3(rb.conv2)
+    if rb.in_channels != rb.out_channels:
+        p.skip_w, p.skip_b = pack_conv1x1(rb.nin_shortcut)
+    ts = rb.time_stack
+    p.t_gn1 = pack_norm(ts.in_layers[0])
+    p.t_w1, p.t_b1 = pack_convt3(ts.in_layers[2])
+    p.t_gn2 = pack_norm(ts.out_layers[0])
+    p.t_w2, p.t_b2 = pack_convt3(ts.out_layers[3])
+    m = float(rb.mix_factor.detach().float().cpu())
+    p.alpha = m if rb.merge_strategy == "fixed" else float(torch.sigmoid(torch.tensor(m)))
+    return p
+
+
+def pack_vae_decoder(dec) -> VAEPack:
+    dev = dec.conv_in.weight.device
+    a = dec.mid.attn_1
+    wv, bv = pack_conv1x1(a.v)
+    attn = AttnPack(C=a.in_channels, norm=pack_norm(a.norm), wq=pack_conv1x1(a.q), wk=pack_conv1x1(a.k), wv=wv, bv=bv,
+                    proj=pack_conv1x1(a.proj_out))
+    mid = [("res", pack_vae_resblock(dec.mid.block_1)), ("attn", attn), ("res", pack_vae_resblock(dec.mid.block_2))]
+    up = []
+    for lvl in dec.up:
+        d = {"blocks": [pack_vae_resblock(b) for b in lvl.block], "upsample": None}
+        if hasattr(lvl, "upsample"):
+            d["upsample"] = pack_conv3x3(lvl.upsample.conv)
+        up.append(d)
+    co = dec.conv_out
+    tw = co.time_mix_conv.weight.detach()
+    return VAEPack(device=dev, z_channels=dec.conv_in.weight.shape[1], z_pad=round_up(dec.conv_in.weight.shape[1], 8),
+                   conv_in=pack_conv3x3(dec.conv_in), mid=mid, up=up, norm_out=pack_norm(dec.norm_out),
+                   conv_out=pack_conv3x3(co), tmix_w=_f(tw.reshape(tw.shape[0], tw.shape[1], 3)), tmix_b=_f(co.time_mix_conv.bias),
+                   out_ch=co.weight.shape[0])

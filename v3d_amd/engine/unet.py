@@ -1,0 +1,176 @@
+"""VideoUNet forward as a flat sequence of C-ABI ops (reference call stack: SURVEY.md §3.3;
+video_model.py:442-493, video_attention.py:230-301, attention.py:556-577).
+
+One activation layout end to end — channels-last bf16 [(b t) * H*W, C] — so none of the reference's layout shuffles
+exist (b c h w <-> b (h w) c, (b t) s c <-> (b s) t c, th.cat of the skip, F.interpolate).  Per evaluation:
+  * 2 embedding MLPs + ONE GEMM for every ResBlock's emb projection + ONE GEMM for every block's (collapsed)
+    1-token cross-attention + one kernel for every AlphaBlender's epilogue coefficients;
+  * per VideoResBlock: 4 GroupNorm(+SiLU) pairs, 2 conv3x3 + 2 temporal 3-tap GEMMs (+1-2 skip GEMMs), with the
+    emb add, residual and alpha-blend fused into GEMM epilogues;
+  * per SpatialVideoTransformer: 1 GroupNorm, 6 LayerNorms, 13 GEMMs (bias / GEGLU / residual / cross-attn vector /
+    alpha-blend in epilogues), one MFMA flash attention over H*W tokens, one temporal attention over T frames.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..ops import GemmCall, get_ops
+from .blocks import Env, Geo, unet_resblock
+from .packing import SVTPack, UNetPack, round_up
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def _cast_rows_bf16(ops, x2d: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
+    """fp32 [n, C] -> bf16 [n, Cpad] (zero padded) with the layout kernel (S = 1)."""
+    n, C = x2d.shape
+    return ops.nchw_to_nhwc_bf16(x2d.float().contiguous().reshape(n, C, 1), 1.0, max(pad_to, round_up(C, 8)))
+
+
+def frame_pos_table(ops, p: SVTPack, B: int, frame_ids) -> torch.Tensor:
+    """time_pos_embed(timestep_embedding(frame index)) per image, [B*T, C] fp32 (video_attention.py:266-276).
+    Depends only on weights and the frame indices, so it is built once per (B, frames) and cached on the pack."""
+    key = (B, tuple(frame_ids))
+    tab = p.tables.get(key)
+    if tab is None:
+        dev = p.proj_in[0].device
+        t = torch.tensor(list(frame_ids), dtype=F32, device=dev)
+        te = ops.timestep_embedding(t, p.C, p.max_period)
+        w0, b0, w2, b2 = p.tpe
+        h = ops.silu_add(ops.linear(te, w0, b0, out_dtype=F32))
+        tab = ops.linear(h, w2, b2, out_dtype=F32).repeat(B, 1).contiguous()
+        p.tables[key] = tab
+    return tab
+
+
+def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
+    ops = env.ops
+    n, S, C, T, B = g.n, g.S, p.C, g.T, g.B
+    sh = env.shard
+    ctx, ctx_ld = env.ctx_all, env.ctx_all.stride(0)
+
+    ga, be, eps = p.norm
+    h = ops.groupnorm(x_in, None, ga, be, n, S, eps=eps, silu=False)
+    x = ops.linear(h, *p.proj_in)
+
+    # ---- spatial BasicTransformerBlock (attention.py:556-577) ----
+    ga, be, eps = p.s_norm1
+    n1 = ops.empty((n * S, C), ops.act_dtype, x.device)
+    ops.layernorm(x, ga, be, n1, eps)
+    qk = ops.linear(n1, p.s_wqk)
+    # V^T[img] = Wv @ LN(x)[img]^T directly out of the projection: keys contiguous for the P.V MFMA, no transpose
+    vT = ops.empty((n, C, S), ops.act_dtype, x.device)
+    ops.gemm(GemmCall(A=p.s_wv, W=n1.view(n, S, C), out=vT, M=C, N=S, K=C, batch=n))
+    a = ops.empty((n * S, C), ops.act_dtype, x.device)
+    ops.attn_spatial(qk[:, :C], qk[:, C:], vT, a, n, S, p.heads, 0.125)
+    # x = attn1 + x, then attn2 (1 context token => a per-image vector, Appendix B-9) folded in the same epilogue
+    x = ops.linear(a, p.s_wo[0], p.s_wo[1], res1=x, add=ctx[:, p.s_ctx_off:], add_rpg=S, add_ld=ctx_ld)
+    ga, be, eps = p.s_norm3
+    n3 = ops.empty((n * S, C), ops.act_dtype, x.device)
+    ops.layernorm(x, ga, be, n3, eps)
+    f = ops.linear(n3, p.s_ff.w1, p.s_ff.b1, geglu=True)
+    x_s = ops.linear(f, p.s_ff.w2, p.s_ff.b2, res1=x)
+
+    # ---- temporal VideoTransformerBlock on x_mix = x + frame embedding (video_attention.py:109-140,286-289) ----
+    frames = range(T) if sh is None else sh.local_frames
+    table = frame_pos_table(ops, p, B, frames)
+    ga, be, eps = p.t_norm_in
+    x_mix = ops.empty((n * S, C), ops.act_dtype, x.device)
+    nin = ops.empty((n * S, C), ops.act_dtype, x.device)
+    ops.layernorm(x_s, ga, be, nin, eps, add=table, add_rpg=S, add_ld=C, xsum_out=x_mix)
+    f = ops.linear(nin, p.t_ff_in.w1, p.t_ff_in.b1, geglu=True)
+    x_t = ops.linear(f, p.t_ff_in.w2, p.t_ff_in.b2, res1=x_mix)
+    ga, be, eps = p.t_norm1
+    ops.layernorm(x_t, ga, be, n1, eps)
+    qkv = ops.linear(n1, p.t_wqkv).view(B, T, S, 3 * C)
+    ta = ops.empty((B, T, S, C), ops.act_dtype, x.device)
+    if sh is None:
+        ops.attn_temporal(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], ta, p.heads, 0.125)
+    else:
+        kv = sh.allgather_frames(qkv[..., C:])             # [B, T_global, S, 2C]
+        ops.attn_temporal(qkv[..., :C], kv[..., :C], kv[..., C:], ta, p.heads, 0.125)
+    # temporal attn2: context = frame-0 context of each sample (video_attention.py:249-253) -> per-sample vector
+    # (rows n.. of ctx_all hold the frame-0 projections, one per sample)
+    x_t = ops.linear(ta.view(n * S, C), p.t_wo[0], p.t_wo[1], res1=x_t, add=ctx[n:, p.t_ctx_off:], add_rpg=S * T,
+                     add_ld=ctx_ld)
+    ga, be, eps = p.t_norm3
+    ops.layernorm(x_t, ga, be, n3, eps)
+    f = ops.linear(n3, p.t_ff.w1, p.t_ff.b1, geglu=True)
+    # AlphaBlender fused: alpha * x_s + (1 - alpha) * (ff + x_t)
+    x = ops.linear(f, p.t_ff.w2, p.t_ff.b2, res1=x_t, res2=x_s, coef=env.coefs[p.mixer], coef_rpg=S)
+    return ops.linear(x, p.proj_out[0], p.proj_out[1], res1=x_in)
+
+
+def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_frames, image_only_indicator, shard=None,
+             context_frame0=None):
+    """x [n, C1, H, W] fp32 (n = cfg * B * T_local), optional per-image `scale` and channel-concat `concat`.
+    `context_frame0` [B, ...]: context of each sample's global frame 0 (defaults to context[::T]; a frame-sharded
+    caller passes it explicitly because frame 0 may live on another rank).
+    Returns an [n, out_channels, H, W] fp32 view of the channels-last result."""
+    ops = get_ops()
+    n, _, H, W = x.shape
+    T = int(num_video_frames) if num_video_frames is not None else 1
+    if shard is not None:
+        T = shard.T_local
+    assert n % T == 0, f"batch {n} is not a multiple of num_video_frames {T}"
+    B = n // T
+    dev = x.device
+    mc = pk.model_channels
+
+    # ---- timestep / label embeddings (video_model.py:455-461) ----
+    te = ops.timestep_embedding(timesteps.reshape(-1).float().contiguous(), mc)
+    w0, b0, w2, b2 = pk.time_embed
+    e = ops.linear(ops.silu_add(ops.linear(te, w0, b0, out_dtype=F32)), w2, b2, out_dtype=F32)
+    lab = None
+    if pk.label_emb is not None:
+        w0, b0, w2, b2 = pk.label_emb
+        yb = _cast_rows_bf16(ops, y.reshape(n, -1), w0.shape[1])
+        lab = ops.linear(ops.silu_add(ops.linear(yb, w0, b0, out_dtype=F32)), w2, b2, out_dtype=F32)
+    semb = ops.silu_add(e, lab)                                             # SiLU(emb): input of every emb_layers
+    emb_all = ops.linear(semb, pk.emb_w, pk.emb_b, out_dtype=F32)           # [n, sum Cout]
+    c2 = context.reshape(n, -1)
+    c0 = c2[::T] if context_frame0 is None else context_frame0.reshape(B, -1)   # time_context = context[::timesteps]
+    cb = _cast_rows_bf16(ops, torch.cat([c2, c0.to(c2.dtype)], dim=0))
+    ctx_all = ops.linear(cb, pk.ctx_w, pk.ctx_b, out_dtype=F32)            # [n + B, sum C]
+    ioi = None
+    if pk.uses_ioi and image_only_indicator is not None:
+        ioi = image_only_indicator.reshape(-1).float().contiguous()
+        assert ioi.numel() == n, f"image_only_indicator has {ioi.numel()} entries for {n} images"
+    coefs = ops.blend_coefs(pk.mix_alpha, pk.mix_kind, ioi, n)
+    env = Env(ops=ops, emb_all=emb_all, ctx_all=ctx_all, coefs=coefs, shard=shard)
+
+    h = ops.pack_input(x.float().contiguous(), scale, None if concat is None else concat.float().contiguous(), pk.in_pad)
+    g = Geo(n=n, B=B, T=T, H=H, W=W)
+
+    def run_stage(items, h, g, skip=None):
+        for kind, p in items:
+            if kind == "conv_in":
+                h = ops.conv3x3(h, p[0], p[1], g.n, g.H, g.W)
+            elif kind == "res":
+                h = unet_resblock(env, g, p, h, skip)
+                skip = None
+            elif kind == "svt":
+                h = run_svt(env, g, p, h)
+            elif kind == "down":
+                h = ops.conv3x3(h, p[0], p[1], g.n, g.H, g.W, stride=2)
+                g = Geo(n=g.n, B=g.B, T=g.T, H=(g.H + 1) // 2, W=(g.W + 1) // 2)
+            elif kind == "up":
+                h = ops.conv3x3(h, p[0], p[1], g.n, g.H, g.W, up=2)
+                g = Geo(n=g.n, B=g.B, T=g.T, H=g.H * 2, W=g.W * 2)
+            else:
+                raise ValueError(kind)
+        return h, g
+
+    hs = []
+    for items in pk.input_stages:
+        h, g = run_stage(items, h, g)
+        hs.append(h)
+    h, g = run_stage(pk.middle, h, g)
+    for items in pk.output_stages:
+        h, g = run_stage(items, h, g, skip=hs.pop())      # th.cat([h, hs.pop()], 1) is consumed split, never built
+    ga, be, eps = pk.out_norm
+    h = ops.groupnorm(h, None, ga, be, g.n, g.S, eps=eps, silu=True)
+    out = ops.conv3x3(h, pk.out_conv[0], pk.out_conv[1], g.n, g.H, g.W, out_dtype=F32)     # [n*S, out_ch] fp32
+    return out.view(n, g.H, g.W, pk.out_channels).permute(0, 3, 1, 2)

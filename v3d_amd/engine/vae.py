@@ -1,0 +1,70 @@
+"""VideoDecoder forward as a flat sequence of C-ABI ops (reference: SURVEY.md §3.4; model.py:715-748,
+temporal_ae.py:64-107, model.py:180-201).
+
+z -> conv_in -> mid (VideoResBlock, AttnBlock, VideoResBlock) -> 4 up levels x 3 VideoResBlocks with a fused
+nearest-2x+conv3x3 between levels -> GroupNorm+swish -> AE3DConv.  Same channels-last bf16 layout and the same
+kernels as the U-Net; the reference decodes in fp32 (disable_first_stage_autocast), here activations are bf16 with
+fp32 accumulation and fp32 GroupNorm statistics (tolerance: tests/test_engine_gpu.py).
+
+AttnBlock (single head, d = C = 512, 4096 tokens): q,k projections, V^T produced directly by a swapped GEMM,
+scores = q k^T * C^-1/2 as a batched GEMM into fp32, row softmax, P V^T^T as a batched GEMM.  The value bias is added
+after P.V (softmax rows sum to 1, so P (V + 1 b^T) = P V + b^T).  With 288 GB of HBM the [T, 4096, 4096] fp32 score
+tensor (1.2 GB for 18 frames) is simply materialised in this round.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..ops import GemmCall, get_ops
+from .blocks import Env, Geo, vae_resblock
+from .packing import AttnPack, VAEPack
+
+F32 = torch.float32
+
+
+def run_vae_attn(env: Env, g: Geo, p: AttnPack, x: torch.Tensor) -> torch.Tensor:
+    ops = env.ops
+    n, S, C = g.n, g.S, p.C
+    ga, be, eps = p.norm
+    hn = ops.groupnorm(x, None, ga, be, n, S, eps=eps, silu=False)
+    q = ops.linear(hn, *p.wq)
+    k = ops.linear(hn, *p.wk)
+    vT = ops.empty((n, C, S), None, x.device)
+    ops.gemm(GemmCall(A=p.wv, W=hn.view(n, S, C), out=vT, M=C, N=S, K=C, batch=n))
+    scores = ops.empty((n, S, S), F32, x.device)
+    ops.gemm(GemmCall(A=q.view(n, S, C), W=k.view(n, S, C), out=scores, M=S, N=S, K=C, batch=n, c_acc=float(C) ** -0.5))
+    prob = ops.empty((n, S, S), None, x.device)
+    ops.softmax_rows(scores, prob)
+    o = ops.empty((n, S, C), None, x.device)
+    ops.gemm(GemmCall(A=prob, W=vT, out=o, M=S, N=C, K=S, batch=n, bias=p.bv))
+    return ops.linear(o.view(n * S, C), p.proj[0], p.proj[1], res1=x)
+
+
+def run_decoder(pk: VAEPack, z: torch.Tensor, T: int, shard=None) -> torch.Tensor:
+    """z [(b t), zc, h, w] fp32 -> [(b t), out_ch, 8h, 8w] fp32 (NCHW, like the reference)."""
+    ops = get_ops()
+    n, _, H, W = z.shape
+    assert n % T == 0, f"{n} latent frames is not a multiple of timesteps={T}"
+    env = Env(ops=ops, shard=shard)
+    g = Geo(n=n, B=n // T, T=T, H=H, W=W)
+    h = ops.nchw_to_nhwc_bf16(z.float().contiguous(), 1.0, pk.z_pad)
+    h = ops.conv3x3(h, pk.conv_in[0], pk.conv_in[1], n, H, W)
+    for kind, p in pk.mid:
+        h = vae_resblock(env, g, p, h) if kind == "res" else run_vae_attn(env, g, p, h)
+    for lvl in reversed(range(len(pk.up))):
+        for p in pk.up[lvl]["blocks"]:
+            h = vae_resblock(env, g, p, h)
+        us = pk.up[lvl]["upsample"]
+        if us is not None:
+            h = ops.conv3x3(h, us[0], us[1], g.n, g.H, g.W, up=2)
+            g = Geo(n=g.n, B=g.B, T=g.T, H=g.H * 2, W=g.W * 2)
+    ga, be, eps = pk.norm_out
+    h = ops.groupnorm(h, None, ga, be, g.n, g.S, eps=eps, silu=True)
+    # AE3DConv: conv3x3 -> out_ch (fp32, padded to 4 columns) then the (3,1,1) frame mix on out_ch channels
+    y = ops.empty((g.n * g.S, 4), F32, z.device)
+    ops.conv3x3(h, pk.conv_out[0], pk.conv_out[1], g.n, g.H, g.W, out=y[:, :pk.out_ch])
+    if shard is None:
+        out = ops.tmix_small(y, pk.tmix_w, pk.tmix_b, g.B, g.T, g.S, pk.out_ch, 0, g.T - 1)
+    else:
+        out = shard.tmix_small(ops, y, pk.tmix_w, pk.tmix_b, g, pk.out_ch)
+    return out.view(g.n, pk.out_ch, g.H, g.W)

@@ -26,7 +26,7 @@ class _GemmArgs(C.Structure):
         ("A", c_vp), ("W", c_vp), ("out", c_vp), ("bias", c_vp), ("add", c_vp), ("res1", c_vp), ("res2", c_vp),
         ("coef", c_vp),
         ("M", c_i64), ("N", c_i64), ("K", c_i64),
-        ("lda", c_i64), ("ldo", c_i64), ("ldr1", c_i64), ("ldr2", c_i64),
+        ("lda", c_i64), ("ldw", c_i64), ("ldo", c_i64), ("ldr1", c_i64), ("ldr2", c_i64),
         ("a_rows", c_i64), ("a_row0", c_i64),
         ("add_rpg", c_i64), ("add_ld", c_i64), ("coef_rpg", c_i64),
         ("c_acc", c_f32), ("c_res1", c_f32), ("c_res2", c_f32),
@@ -45,6 +45,7 @@ SIGNATURES = {
     "v3d_last_error": (C.c_char_p, []),
     "v3d_device_info": (c_i32, [c_vp]),
     "v3d_gemm": (c_i32, [C.POINTER(_GemmArgs), c_vp]),
+    "v3d_sizeof_gemm_args": (c_i32, []),
     "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp]),
     "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i64,
                                     c_f64, c_f32, c_i32, c_vp]),
@@ -82,6 +83,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     v = lib.v3d_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"libv3d_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild the extension")
+    if lib.v3d_sizeof_gemm_args() != C.sizeof(_GemmArgs):
+        raise RuntimeError(f"v3d_gemm_args layout mismatch: library {lib.v3d_sizeof_gemm_args()} B vs binding {C.sizeof(_GemmArgs)} B")
     return lib
 
 
@@ -137,8 +140,9 @@ class HipOps(OpsBase):
         a = _GemmArgs()
         self._req(g.A, bf, "gemm.A")
         self._req(g.W, bf, "gemm.W")
-        if g.W.stride(-2) != g.K:
-            raise RuntimeError("gemm.W rows must be densely packed (stride == K)")
+        ldw = g.W.stride(-2)
+        if g.W.dim() == 3 and g.mode != 0 and g.W.stride(0) != g.N * ldw:
+            raise RuntimeError("gemm.W: taps must be densely stacked")
         out_fp32 = g.out.dtype == f32
         self._req(g.out, f32 if out_fp32 else bf, "gemm.out")
         a.A, a.W, a.out = g.A.data_ptr(), g.W.data_ptr(), g.out.data_ptr()
@@ -149,6 +153,7 @@ class HipOps(OpsBase):
         a.coef = _ptr(None if g.coef is None else self._req_c(g.coef, f32, "gemm.coef"))
         a.M, a.N, a.K = g.M, g.N, g.K
         a.lda = g.A.stride(-2) if g.A.dim() >= 2 else g.K
+        a.ldw = ldw
         a.ldo = g.out.stride(-2)
         a.ldr1 = 0 if g.res1 is None else g.res1.stride(-2)
         a.ldr2 = 0 if g.res2 is None else g.res2.stride(-2)

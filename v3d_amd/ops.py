@@ -64,26 +64,27 @@ class OpsBase:
     """Primitive op names == C-ABI entry points (without the v3d_ prefix).  Subclasses implement them."""
 
     name = "base"
+    act_dtype = torch.bfloat16   # storage dtype of activations / packed weights (the emulator can run an exact fp32 mode)
 
     # ---- allocation -------------------------------------------------------------------------------
-    def empty(self, shape, dtype=torch.bfloat16, device=None):
-        return torch.empty(shape, dtype=dtype, device=device if device is not None else self.device)
+    def empty(self, shape, dtype=None, device=None):
+        return torch.empty(shape, dtype=dtype or self.act_dtype, device=device if device is not None else self.device)
 
     def zeros(self, shape, dtype=torch.float32, device=None):
         return torch.zeros(shape, dtype=dtype, device=device if device is not None else self.device)
 
     # ---- composite helpers shared by every backend ------------------------------------------------
-    def linear(self, x2d, w, bias=None, *, out=None, out_dtype=torch.bfloat16, geglu=False, **epi):
+    def linear(self, x2d, w, bias=None, *, out=None, out_dtype=None, geglu=False, **epi):
         """x2d [M, K] (row-strided ok) @ w[N, K]^T with the fused epilogue of v3d_gemm."""
         M, K = x2d.shape
         N = w.shape[-2]
         n_out = N // 2 if geglu else N
         if out is None:
-            out = self.empty((M, n_out), out_dtype, x2d.device)
+            out = self.empty((M, n_out), out_dtype or self.act_dtype, x2d.device)
         self.gemm(GemmCall(A=x2d, W=w, out=out, M=M, N=N, K=K, bias=bias, geglu=geglu, **epi))
         return out
 
-    def conv3x3(self, x, w, bias, n_img, Hin, Win, *, stride=1, up=1, out=None, out_dtype=torch.bfloat16, **epi):
+    def conv3x3(self, x, w, bias, n_img, Hin, Win, *, stride=1, up=1, out=None, out_dtype=None, **epi):
         """x [n_img*Hin*Win, Cin] channels-last, w [9, Cout, Cin] -> [n_img*Hout*Wout, Cout]."""
         Hl, Wl = Hin * up, Win * up
         Hout, Wout = (Hl + 2 - 3) // stride + 1, (Wl + 2 - 3) // stride + 1
@@ -91,12 +92,12 @@ class OpsBase:
         N = w.shape[-2]
         M = n_img * Hout * Wout
         if out is None:
-            out = self.empty((M, N), out_dtype, x.device)
+            out = self.empty((M, N), out_dtype or self.act_dtype, x.device)
         self.gemm(GemmCall(A=x, W=w, out=out, M=M, N=N, K=K, bias=bias, mode=GEMM_CONV3X3, Hin=Hin, Win=Win,
                            Hout=Hout, Wout=Wout, stride=stride, up=up, **epi))
         return out
 
-    def convt3(self, x, w, bias, T, S, *, tmin=0, tmax=None, a_row0=0, M=None, out=None, out_dtype=torch.bfloat16, **epi):
+    def convt3(self, x, w, bias, T, S, *, tmin=0, tmax=None, a_row0=0, M=None, out=None, out_dtype=None, **epi):
         """Temporal 3-tap conv over frames: x [(b t) * S (+halo), C], w [3, Cout, Cin]."""
         K = x.shape[-1]
         N = w.shape[-2]
@@ -105,7 +106,7 @@ class OpsBase:
         if tmax is None:
             tmax = T - 1
         if out is None:
-            out = self.empty((M, N), out_dtype, x.device)
+            out = self.empty((M, N), out_dtype or self.act_dtype, x.device)
         self.gemm(GemmCall(A=x, W=w, out=out, M=M, N=N, K=K, bias=bias, mode=GEMM_CONVT3, T=T, S=S, tmin=tmin,
                            tmax=tmax, a_row0=a_row0, **epi))
         return out
@@ -125,7 +126,7 @@ class OpsBase:
         if count_imgs is None:
             count_imgs = imgs_per_stat
         count = float(count_imgs) * S * (C // groups)
-        out = self.empty((n_img * S, C), torch.bfloat16, x1.device)
+        out = self.empty((n_img * S, C), self.act_dtype, x1.device)
         self.groupnorm_apply(x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu)
         return out
 
