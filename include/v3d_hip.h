@@ -173,9 +173,10 @@ int v3d_blend_coefs(const float* alpha, const int32_t* kind, const float* ioi, f
 /* layout / dtype moves: fp32 NCHW <-> bf16 channels-last (zero-pad channels up to Cpad) */
 int v3d_nchw_to_nhwc_bf16(const float* x, float scale, void* out_bf16, int64_t n, int64_t C, int64_t S, int64_t Cpad, v3d_stream_t stream);
 /* AE3DConv.time_mix_conv (temporal_ae.py:94-107): Conv3d (3,1,1) on Cc<=4 channels over frames of a fp32 channels-last
- * [B*T][S][ld] map, output fp32 NCHW [B*T][Cc][S]; w[co][ci][3], b[co]; tmin/tmax as in CONVT3 */
+ * [B*T][S][ld] map, output fp32 NCHW [B*T][Cc][S]; w[co][ci][3], b[co]; tmin/tmax as in CONVT3; row0 = rows in front
+ * of frame 0 (a leading halo frame under frame sharding) */
 int v3d_tmix_small(const float* x, int64_t ld, const float* w, const float* b, float* out, int64_t B, int32_t T,
-                   int64_t S, int32_t Cc, int32_t tmin, int32_t tmax, v3d_stream_t stream);
+                   int64_t S, int32_t Cc, int32_t tmin, int32_t tmax, int64_t row0, v3d_stream_t stream);
 /* dst_bf16[r][dst_off + c] = src_bf16[r][src_off + c], c < C  (strided 2-D bf16 copy; C % 8 == 0) */
 int v3d_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t C, v3d_stream_t stream);
 

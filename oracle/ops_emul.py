@@ -223,15 +223,17 @@ class EmulOps(OpsBase):
     def nchw_to_nhwc_bf16(self, x, scale, Cpad):
         return self.pack_input(x.float() * scale, None, None, Cpad)
 
-    def tmix_small(self, x, w, b, B, T, S, Cc, tmin, tmax):
-        xf = x[:, :Cc].float().reshape(B * T, S, Cc)
+    def tmix_small(self, x, w, b, B, T, S, Cc, tmin, tmax, row0=0):
+        nfr = x.shape[0] // S
+        xf = x[:, :Cc].float().reshape(nfr, S, Cc)
+        f0 = row0 // S
         out = torch.zeros(B * T, Cc, S, dtype=torch.float32, device=x.device)
         f = torch.arange(B * T, device=x.device)
         t = f % T
         for dt in range(3):
             tt = t + dt - 1
             valid = ((tt >= tmin) & (tt <= tmax)).float()
-            src = (f + dt - 1).clamp(0, B * T - 1)
+            src = (f + f0 + dt - 1).clamp(0, nfr - 1)
             xs = xf[src] * valid[:, None, None]                        # [f, s, ci]
             out += torch.einsum("fsi,oi->fos", xs, w[:, :, dt].float())
         return out + b.float()[None, :, None]

@@ -130,7 +130,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float scale, bf
 
 // Conv3d (3,1,1) over frames on <= 4 channels; one thread per (frame, s)
 __global__ void tmix_small_kernel(const float* __restrict__ x, long long ld, const float* __restrict__ w, const float* __restrict__ b,
-                                  float* __restrict__ out, long long B, int T, long long S, int Cc, int tmin, int tmax) {
+                                  float* __restrict__ out, long long B, int T, long long S, int Cc, int tmin, int tmax, long long row0) {
     const long long total = B * T * S;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long s = i % S;
@@ -143,7 +143,7 @@ __global__ void tmix_small_kernel(const float* __restrict__ x, long long ld, con
         for (int dt = 0; dt < 3; ++dt) {
             const int tt = t + dt - 1;
             if (tt < tmin || tt > tmax) continue;
-            const float* xp = x + ((f + dt - 1) * S + s) * ld;
+            const float* xp = x + (row0 + (f + dt - 1) * S + s) * ld;
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci) {
                 if (ci < Cc) {
@@ -240,10 +240,10 @@ extern "C" int v3d_nchw_to_nhwc_bf16(const float* x, float scale, void* out_bf16
 }
 
 extern "C" int v3d_tmix_small(const float* x, int64_t ld, const float* w, const float* b, float* out, int64_t B, int32_t T,
-                              int64_t S, int32_t Cc, int32_t tmin, int32_t tmax, v3d_stream_t stream) {
-    V3D_REQUIRE(x && w && b && out && B > 0 && T > 0 && S > 0, "v3d_tmix_small: bad args");
+                              int64_t S, int32_t Cc, int32_t tmin, int32_t tmax, int64_t row0, v3d_stream_t stream) {
+    V3D_REQUIRE(x && w && b && out && B > 0 && T > 0 && S > 0 && row0 >= 0, "v3d_tmix_small: bad args");
     V3D_REQUIRE(Cc >= 1 && Cc <= 4 && ld >= Cc, "v3d_tmix_small: Cc must be in [1,4]");
-    hipLaunchKernelGGL(tmix_small_kernel, dim3(nblocks(B * T * S)), dim3(256), 0, ST, x, (long long)ld, w, b, out, (long long)B, T, (long long)S, Cc, tmin, tmax);
+    hipLaunchKernelGGL(tmix_small_kernel, dim3(nblocks(B * T * S)), dim3(256), 0, ST, x, (long long)ld, w, b, out, (long long)B, T, (long long)S, Cc, tmin, tmax, (long long)row0);
     return v3d_check_launch("v3d_tmix_small");
 }
 

@@ -64,7 +64,7 @@ SIGNATURES = {
     "v3d_axpb_f32": (c_i32, [c_vp, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "v3d_blend_coefs": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
-    "v3d_tmix_small": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "v3d_tmix_small": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "v3d_copy2d_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
 }
 
@@ -327,12 +327,12 @@ class HipOps(OpsBase):
                     "v3d_nchw_to_nhwc_bf16")
         return out
 
-    def tmix_small(self, x, w, b, B, T, S, Cc, tmin, tmax):
+    def tmix_small(self, x, w, b, B, T, S, Cc, tmin, tmax, row0=0):
         f32 = torch.float32
         self._req(x, f32, "tmix.x"); self._req_c(w, f32, "tmix.w"); self._req_c(b, f32, "tmix.b")
         out = self.empty((B * T, Cc, S), f32, x.device)
         self._check(self.lib.v3d_tmix_small(x.data_ptr(), x.stride(-2), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, T, S, Cc,
-                                            tmin, tmax, self._stream()), "v3d_tmix_small")
+                                            tmin, tmax, row0, self._stream()), "v3d_tmix_small")
         return out
 
     def copy2d_bf16(self, src, dst):
