@@ -1,0 +1,83 @@
+"""Frame sharding (v3d_amd/dist.py) on CPU: world_size-2 gloo processes, engine executed with the exact-mode op emulator,
+sharded result == unsharded reference fixture.  T = 3 frames over 2 ranks is the UNEVEN split (2 + 1), so halo exchange at
+a shard boundary, padded all-gather, GroupNorm-stat all-reduce with a global count and the frame-0 context plumbing are all
+exercised.  (The N > 1 GPU path uses the same code with backend "nccl" == RCCL.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tiny import TINY, build_decoder, build_unet, decoder_latents, tiny_unet_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    torch.set_grad_enabled(False)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.ops_emul import EmulOps
+        from v3d_amd.dist import FrameShard, frame_partition, sharded_unet_eval
+        from v3d_amd.engine.vae import run_decoder
+        from v3d_amd.ops import use_backend
+        p = TINY
+        T = p["T"]
+        golden = torch.load(os.path.join(ROOT, "tests", "golden", "v3d_tiny.pt"))
+        sh = FrameShard(T)
+        assert [len(r) for r in frame_partition(18, 8)] == [3, 3, 2, 2, 2, 2, 2, 2]
+        _, _, _, x8, ts, ctx, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+        ioi = torch.zeros(2, T)
+        ioi[1, 1] = 1.0
+        B = 2
+        with use_backend(EmulOps("cpu", exact=True)):
+            net = build_unet()
+            out_loc = sharded_unet_eval(net, sh, sh.take_frames(x8, B), None, None, sh.take_frames(ts, B), ctx,
+                                        sh.take_frames(y, B), sh.take_frames(ioi.reshape(-1), B))
+            out = sh.gather_frames_out(out_loc.contiguous(), B)
+            err_unet = ((out - golden["unet_out_ioi"]).abs().max() / golden["unet_out_ioi"].abs().max()).item()
+            dec = build_decoder()
+            z = decoder_latents(T)
+            fr_loc = run_decoder(dec.packed(), sh.take_frames(z, 1), sh.T_local, shard=sh)
+            fr = sh.gather_frames_out(fr_loc.contiguous(), 1)
+            err_dec = ((fr - golden["dec_out"]).abs().max() / golden["dec_out"].abs().max()).item()
+        q.put((rank, sh.T_local, err_unet, err_dec))
+    except Exception as e:  # report instead of leaving the parent waiting on the queue
+        import traceback
+        q.put((rank, -1, traceback.format_exc(), str(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_uneven_frame_shard_matches_unsharded():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    for r in res:
+        assert r[1] >= 0, f"rank {r[0]} failed:\n{r[2]}"
+    res.sort()
+    assert [r[1] for r in res] == [2, 1]          # uneven 2 + 1 split
+    for rank, _, e_unet, e_dec in res:
+        assert e_unet <= 5e-5, f"rank {rank}: sharded U-Net differs from the unsharded reference fixture: {e_unet}"
+        assert e_dec <= 5e-5, f"rank {rank}: sharded VAE decode differs from the unsharded reference fixture: {e_dec}"

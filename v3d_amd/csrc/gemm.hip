@@ -1,17 +1,21 @@
 // v3d_gemm: multi-tap bf16 MFMA contraction for gfx950 (see include/v3d_hip.h for the op contract).
 //
-// One kernel family covers nn.Linear / 1x1 conv (1 tap), Conv2d 3x3 incl. stride-2 and fused nearest-2x
-// upsample (9 taps, implicit GEMM over channels-last pixels) and the (3,1,1) temporal conv (3 taps along the
-// frame stride).  Tile: BM x BN x 64, 256 threads = 4 waves (2 x 2), v_mfma_f32_16x16x32_bf16 with the WEIGHT
-// fragment as the A operand so that each lane ends up with 4 consecutive output channels of one pixel
-// (8-byte bf16 stores, float4 bias / per-image vector loads).  Operands are staged HBM -> VGPR -> LDS with
-// the next tile's global loads in flight during the MFMAs of the current one; LDS rows are padded by 16 B.
+// One kernel family covers nn.Linear / 1x1 conv (1 tap), Conv2d 3x3 incl. stride-2 and fused nearest-2x upsample
+// (9 taps, implicit GEMM over channels-last pixels) and the (3,1,1) temporal conv (3 taps along the frame stride).
+// v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand, so each lane ends up with 4 consecutive output
+// channels of one pixel (8-byte bf16 stores, float4 bias loads).
+//
+// Main loop "v2" (default): HBM/L2 -> LDS by direct LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into an NS-deep
+// ring of BK=32 stages; NS-1 stages are in flight while one is consumed; counted s_waitcnt vmcnt(N) + one raw s_barrier
+// per stage (never vmcnt(0) inside the loop).  LDS rows are 64 B; the 16-byte chunk position of a row is XOR-swizzled
+// (applied on the per-lane SOURCE address, the LDS-DMA destination being lane-linear) so every ds_read_b128 lane group
+// hits 16 distinct 16-byte slots.  Conv zero padding / M,N,K tails read from a 64-byte zero page instead of branching.
+// Main loop "v1" (V3D_GEMM_IMPL=1, kept for A/B runs): register-staged double buffer with buffer loads.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
-
-constexpr int BK = 64;
-constexpr int LROW = BK + 8;  // padded LDS row (bf16 elements) = 144 B, keeps 16-B alignment
 
 struct GP {
     const bf16_t* A;
@@ -35,6 +39,8 @@ struct GP {
     long long sA, sW, sO;
     int mt, nt;  // tile counts
 };
+
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page[16] = {0};
 
 template <int MODE>
 struct RowInfo {};
@@ -101,134 +107,22 @@ constexpr int ntaps() {
     return MODE == V3D_GEMM_LINEAR ? 1 : (MODE == V3D_GEMM_CONV3X3 ? 9 : 3);
 }
 
-template <int BM, int BN, int MODE, bool GEGLU>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GP p) {
-    constexpr int AI = BM / 32;      // 16-B chunks of A per thread per stage
-    constexpr int BI = BN / 32;
-    constexpr int WM = BM / 2;       // wave tile rows (pixels)
-    constexpr int WN = BN / 2;       // wave tile cols (out channels)
-    constexpr int MF = WM / 16;      // m fragments per wave
-    constexpr int NF = WN / 16;      // n fragments per wave
-    __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LROW];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LROW];
+// XCD-aware bijective remap of a 1-D grid: consecutive logical tiles share an XCD (and its L2)
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware bijective remap of the 1-D grid: consecutive logical tiles share an XCD (and its L2)
-    const int nblk = p.mt * p.nt;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nblk >> 3, r = nblk & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int tile_n = bid % p.nt;
-    const int tile_m = bid / p.nt;
-    const long long m0 = (long long)tile_m * BM;
-    const long long n0 = (long long)tile_n * BN;
-
-    const long long z = blockIdx.y;
-    // Buffer descriptors: out-of-range offsets (kInvalid) return zeros in hardware, so conv zero padding, the
-    // M/N/K tails and the frame-boundary taps need no branches and no select on the loaded data.
-    const bufrsrc_t rsA = make_rsrc(p.A + z * p.sA, p.a_bytes);
-    const bufrsrc_t rsW = make_rsrc(p.W + z * p.sW, p.w_bytes);
-
-    // global->LDS staging assignment: thread owns 16-B chunk column kc of rows r0 + 32*i
-    const int kc = tid & 7;
-    const int r0 = tid >> 3;
-
-    RowInfo<MODE> ri[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) ri[i].init(p, m0 + r0 + 32 * i);
-
-    u32x4 ra[AI], rb[BI];
-    unsigned aoff[AI], boff[BI];   // byte offsets of this thread's chunks for the current tap (k0 = 0), or kInvalid
-
-    const int ksteps = (int)((p.K + BK - 1) / BK);
-    const int nsteps = ksteps * ntaps<MODE>();
-
-    int ld_tap = 0, ld_k0 = 0;  // position of the NEXT tile to load
-    auto set_tap = [&](int tap) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            long long srow;
-            const bool ok = ri[i].tap(p, tap, srow);
-            aoff[i] = ok ? (unsigned)(((srow + p.a_row0) * p.lda + kc * 8) * 2) : kInvalid;
-        }
-#pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const long long n = n0 + r0 + 32 * i;
-            boff[i] = (n < p.N) ? (unsigned)((((long long)tap * p.N + n) * p.ldw + kc * 8) * 2) : kInvalid;
-        }
-    };
-    set_tap(0);
-    auto gload = [&]() {
-        const bool kok = (ld_k0 + kc * 8) < p.K;
-        const unsigned kb = (unsigned)ld_k0 * 2u;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) ra[i] = buf_load16(rsA, (kok && aoff[i] != kInvalid) ? aoff[i] + kb : kInvalid);
-#pragma unroll
-        for (int i = 0; i < BI; ++i) rb[i] = buf_load16(rsW, (kok && boff[i] != kInvalid) ? boff[i] + kb : kInvalid);
-        ld_k0 += BK;
-        if (ld_k0 >= p.K) {
-            ld_k0 = 0;
-            ++ld_tap;
-            if (ntaps<MODE>() > 1 && ld_tap < ntaps<MODE>()) set_tap(ld_tap);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<u32x4*>(&sA[buf][(r0 + 32 * i) * LROW + kc * 8]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<u32x4*>(&sB[buf][(r0 + 32 * i) * LROW + kc * 8]) = rb[i];
-    };
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    gload();
-    lstore(0);
-    __syncthreads();
-
-    const int frow = lane & 15;        // row inside a 16-row fragment
-    const int fk = (lane >> 4) * 8;    // k offset (8 bf16 = 16 B) inside a 32-wide k slice
-
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        if (step + 1 < nsteps) gload();
-#pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 xf[MF], wf[NF];
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-                xf[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][(wm * WM + i * 16 + frow) * LROW + kk * 32 + fk]);
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-                wf[j] = *reinterpret_cast<const bf16x8*>(&sB[buf][(wn * WN + j * 16 + frow) * LROW + kk * 32 + fk]);
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
-        if (step + 1 < nsteps) lstore(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds, per fragment, 4 consecutive n (= (lane>>4)*4 + r) of pixel m = lane&15 ----
+// ---- epilogue shared by both main loops --------------------------------------------------------------------------
+// The wave holds MF x NF fragments; per fragment a lane owns 4 consecutive n (= (lane>>4)*4 + r) of pixel m = lane&15.
+template <int MF, int NF, bool GEGLU>
+__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane) {
     const long long Nout = GEGLU ? p.N / 2 : p.N;
     const bool vec_ok = (p.ldo % 4 == 0) && (!p.res1 || p.ldr1 % 4 == 0) && (!p.res2 || p.ldr2 % 4 == 0);
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        const long long m = m0 + wm * WM + i * 16 + (lane & 15);
+        const long long m = mw0 + i * 16 + (lane & 15);
         if (m >= p.M) continue;
         float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
         if (p.coef) {
@@ -241,11 +135,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GP p) {
 #pragma unroll
         for (int j = 0; j < NF; j += 1) {
             if (GEGLU && (j & 1)) continue;  // gate fragments are consumed with their value fragment
-            const long long np = n0 + wn * WN + j * 16 + (lane >> 4) * 4;  // packed weight-row index
+            const long long np = nw0 + j * 16 + (lane >> 4) * 4;  // packed weight-row index
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            if (np < p.N) {
+            if (np + 3 < p.N) {
+                if (p.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + np);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                if (addv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += addv[np + r];
+                }
+            } else if (np < p.N) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (np + r < p.N) {
@@ -318,13 +221,314 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GP p) {
     }
 }
 
+// =====================================================================================================================
+// v2: LDS-DMA ring pipeline
+// =====================================================================================================================
+// A stage holds KS k-slices of 32: LDS rows of 64 B (KS=1) or 128 B (KS=2).
+// Chunk-position swizzle per 4-row block b = (row >> 2) & 3: {0, 2, 3, 1}.  With 64-byte rows the 256-byte LDS bank row
+// holds 4 rows x 4 chunks; the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) read rows
+// {0-3,12-15} at chunk c and rows {4-11} at chunk c^1: positions {f0, f3, 1^f1, 1^f2} and {f1, f2, 1^f0, 1^f3} (and the
+// same XOR 2 for the upper half-wave) are all distinct for f = {0,2,3,1} -> 16 distinct slots per group, no conflicts.
+// With 128-byte rows (2 rows per bank row, 8 chunk positions) the same argument gives f(row) = (row >> 1) & 7.
+template <int KS>
+__device__ __forceinline__ int swz_row(int row) {
+    if (KS == 1) return (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+    return (row >> 1) & 7;
+}
+
+template <int BM, int BN, int WGM, int WGN, int NS, int KS, int MODE, bool GEGLU>
+__global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) void gemm_kernel_v2(GP p) {
+    constexpr int BK2 = 32 * KS;             // k extent of one stage
+    constexpr int ROWB = BK2 * 2;            // bytes per LDS row
+    constexpr int RPP = 1024 / ROWB;         // rows per 1-KiB piece (one wave-wide LDS-DMA): 16 or 8
+    constexpr int CPR = ROWB / 16;           // 16-byte chunks per row: 4 or 8
+    constexpr int NW = WGM * WGN;            // waves per block
+    constexpr int WM = BM / WGM;             // wave tile rows (pixels)
+    constexpr int WN = BN / WGN;             // wave tile cols (out channels)
+    constexpr int MF = WM / 16, NF = WN / 16;
+    constexpr int APW = BM / RPP / NW;       // A pieces per wave per stage
+    constexpr int BPW = BN / RPP / NW;
+    static_assert(APW >= 1 && BPW >= 1 && APW * NW * RPP == BM && BPW * NW * RPP == BN, "tile / wave-count mismatch");
+    constexpr int PIECES = APW + BPW;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    static_assert(PIECES * (NS - 2) < 64, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE_BYTES];   // the ONLY __shared__ object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int bid = xcd_remap(blockIdx.x, p.mt * p.nt);
+    const int tile_n = bid % p.nt;
+    const int tile_m = bid / p.nt;
+    const long long m0 = (long long)tile_m * BM;
+    const long long n0 = (long long)tile_n * BN;
+    const long long z = blockIdx.y;
+    const bf16_t* __restrict__ A = p.A + z * p.sA;
+    const bf16_t* __restrict__ W = p.W + z * p.sW;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+    // ---- LDS-DMA source addressing: lane l of a piece covers row (l / CPR), LDS chunk position (l % CPR) of that row;
+    //      the position holds logical k-chunk pos ^ swz(row)  ->  this lane loads that logical chunk.  The swizzle of a
+    //      row only depends on its index modulo 16, and every piece starts at a multiple of RPP rows.
+    const int prow = lane / CPR;
+    int kchunk_a[APW], kchunk_b[BPW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) kchunk_a[i] = (lane % CPR) ^ swz_row<KS>((wave + NW * i) * RPP + prow);
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) kchunk_b[i] = (lane % CPR) ^ swz_row<KS>((wave + NW * i) * RPP + prow);
+    RowInfo<MODE> ri[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) ri[i].init(p, m0 + (wave + NW * i) * RPP + prow);
+    const bf16_t* arow[APW];   // source row pointer (+ k-chunk) for the current tap, or nullptr (-> zero page)
+    const bf16_t* brow[BPW];
+    auto set_tap = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            long long s;
+            const bool ok = ri[i].tap(p, tap, s);
+            arow[i] = ok ? A + (s + p.a_row0) * p.lda + kchunk_a[i] * 8 : nullptr;
+        }
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const long long n = n0 + (wave + NW * i) * RPP + prow;
+            brow[i] = (n < p.N) ? W + ((long long)tap * p.N + n) * p.ldw + kchunk_b[i] * 8 : nullptr;
+        }
+    };
+    const int ksteps = (int)((p.K + BK2 - 1) / BK2);
+    const int nsteps = ksteps * ntaps<MODE>();
+    int ld_tap = 0, ld_k0 = 0, ld_step = 0;
+    set_tap(0);
+    auto issue = [&](int stage) {
+        const bool live = ld_step < nsteps;
+        unsigned char* sbase = lds + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const bool kok = live && (ld_k0 + kchunk_a[i] * 8 < p.K);
+            const bf16_t* g = (kok && arow[i]) ? arow[i] + ld_k0 : zero;
+            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sbase + (wave + NW * i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const bool kok = live && (ld_k0 + kchunk_b[i] * 8 < p.K);
+            const bf16_t* g = (kok && brow[i]) ? brow[i] + ld_k0 : zero;
+            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sbase + BM * ROWB + (wave + NW * i) * 1024), 16, 0, 0);
+        }
+        ++ld_step;
+        ld_k0 += BK2;
+        if (ld_k0 >= p.K) {
+            ld_k0 = 0;
+            ++ld_tap;
+            if (ntaps<MODE>() > 1 && ld_tap < ntaps<MODE>()) set_tap(ld_tap);
+        }
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row (lane & 15) of a 16-row fragment, logical chunk kk*4 + (lane >> 4), stored at chunk ^ swz
+    int frag_off[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) frag_off[kk] = (lane & 15) * ROWB + (((kk * 4 + (lane >> 4)) ^ swz_row<KS>(lane & 15)) * 16);
+    const int a_base = wm * WM * ROWB;
+    const int b_base = BM * ROWB + wn * WN * ROWB;
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+
+    for (int t = 0; t < nsteps; ++t) {
+        // this wave's pieces of stage t have landed when at most PIECES*(NS-2) newer DMA ops are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (NS - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone finished reading stage (t-1) % NS
+        asm volatile("" ::: "memory");
+        issue((t + NS - 1) % NS);       // refill the stage consumed in the previous iteration
+        const unsigned char* sb = lds + (t % NS) * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            bf16x8 xf[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + frag_off[kk] + i * 16 * ROWB);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_base + frag_off[kk] + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (dummy) tail DMAs before LDS is released
+
+    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+}
+
+// =====================================================================================================================
+// v1: register-staged double buffer (buffer loads with hardware bounds checking)
+// =====================================================================================================================
+constexpr int BK = 64;
+constexpr int LROW = BK + 8;  // padded LDS row (bf16 elements) = 144 B, keeps 16-B alignment
+
+template <int BM, int BN, int MODE, bool GEGLU>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
+    constexpr int AI = BM / 32;
+    constexpr int BI = BN / 32;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MF = WM / 16, NF = WN / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][BN * LROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, p.mt * p.nt);
+    const int tile_n = bid % p.nt;
+    const int tile_m = bid / p.nt;
+    const long long m0 = (long long)tile_m * BM;
+    const long long n0 = (long long)tile_n * BN;
+    const long long z = blockIdx.y;
+    const bufrsrc_t rsA = make_rsrc(p.A + z * p.sA, p.a_bytes);
+    const bufrsrc_t rsW = make_rsrc(p.W + z * p.sW, p.w_bytes);
+    const int kc = tid & 7;
+    const int r0 = tid >> 3;
+    RowInfo<MODE> ri[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ri[i].init(p, m0 + r0 + 32 * i);
+    u32x4 ra[AI], rb[BI];
+    unsigned aoff[AI], boff[BI];
+    const int ksteps = (int)((p.K + BK - 1) / BK);
+    const int nsteps = ksteps * ntaps<MODE>();
+    int ld_tap = 0, ld_k0 = 0;
+    auto set_tap = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            long long srow;
+            const bool ok = ri[i].tap(p, tap, srow);
+            aoff[i] = ok ? (unsigned)(((srow + p.a_row0) * p.lda + kc * 8) * 2) : kInvalid;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const long long n = n0 + r0 + 32 * i;
+            boff[i] = (n < p.N) ? (unsigned)((((long long)tap * p.N + n) * p.ldw + kc * 8) * 2) : kInvalid;
+        }
+    };
+    set_tap(0);
+    auto gload = [&]() {
+        const bool kok = (ld_k0 + kc * 8) < p.K;
+        const unsigned kb = (unsigned)ld_k0 * 2u;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[i] = buf_load16(rsA, (kok && aoff[i] != kInvalid) ? aoff[i] + kb : kInvalid);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = buf_load16(rsW, (kok && boff[i] != kInvalid) ? boff[i] + kb : kInvalid);
+        ld_k0 += BK;
+        if (ld_k0 >= p.K) {
+            ld_k0 = 0;
+            ++ld_tap;
+            if (ntaps<MODE>() > 1 && ld_tap < ntaps<MODE>()) set_tap(ld_tap);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(&sA[buf][(r0 + 32 * i) * LROW + kc * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<u32x4*>(&sB[buf][(r0 + 32 * i) * LROW + kc * 8]) = rb[i];
+    };
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gload();
+    lstore(0);
+    __syncthreads();
+    const int frow = lane & 15;
+    const int fk = (lane >> 4) * 8;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) gload();
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 xf[MF], wf[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+                xf[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][(wm * WM + i * 16 + frow) * LROW + kk * 32 + fk]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8*>(&sB[buf][(wn * WN + j * 16 + frow) * LROW + kk * 32 + fk]);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+}
+
+int impl_choice() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("V3D_GEMM_IMPL");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+// tuning knob for A/B sweeps (tools/gemm_sweep.py): forces one v2 tile / pipeline configuration (-1 = heuristic)
+int cfg_choice() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("V3D_GEMM_CFG");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 template <int BM, int BN, int MODE, bool GEGLU>
 int launch(const GP& p0, int batch, hipStream_t st) {
     GP p = p0;
     p.mt = (int)((p.M + BM - 1) / BM);
     p.nt = (int)((p.N + BN - 1) / BN);
     dim3 grid((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+    if (impl_choice() == 1) {
+        hipLaunchKernelGGL((gemm_kernel_v1<BM, BN, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+        return v3d_check_launch("v3d_gemm");
+    }
+    int cfg = cfg_choice();
+    if (cfg < 0) {
+        // measured on MI355X (profiles/r01_gemm_sweep.txt): short contractions (<= 40 stages of 32: every K <= 1280 linear,
+        // the 128-channel VAE convs) are bound by per-tile fill/drain bubbles -> more co-resident blocks (3-deep ring of
+        // BK 32, 48 KiB LDS, 3 blocks/CU) wins; long ones prefer fewer barriers per MFMA (2 stages of BK 64).
+        const long long stages32 = (long long)ntaps<MODE>() * ((p.K + 31) / 32);
+        cfg = stages32 <= 40 ? 2 : 1;
+    }
+    switch (cfg) {
+        case 1:   // BK 64 stages, 2 deep (one in flight)
+            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            break;
+        case 2:   // BK 32 stages, 3 deep: 3 blocks / CU
+            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 3, 1, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            break;
+        case 3:   // 256 x 128 tile, 8 waves (4 x 2), BK 32 x 4 stages (N tiles of 64 keep the 4-wave kernel)
+        case 4:   // 256 x 128 tile, 8 waves, BK 64 x 3 stages
+            if constexpr (BN == 128) {
+                p.mt = (int)((p.M + 255) / 256);
+                dim3 g2((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
+                if (cfg == 3)
+                    hipLaunchKernelGGL((gemm_kernel_v2<256, BN, 4, 2, 4, 1, MODE, GEGLU>), g2, dim3(512), 0, st, p);
+                else
+                    hipLaunchKernelGGL((gemm_kernel_v2<256, BN, 4, 2, 3, 2, MODE, GEGLU>), g2, dim3(512), 0, st, p);
+                break;
+            }
+            [[fallthrough]];
+        default:  // cfg 0: BK 32 stages, 4 deep
+            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 4, 1, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+    }
     return v3d_check_launch("v3d_gemm");
 }
 
@@ -350,12 +554,13 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     V3D_REQUIRE(!a->coef || a->coef_rpg > 0, "v3d_gemm: coef_rpg must be > 0");
     V3D_REQUIRE(a->sA % 8 == 0 && a->sW % 8 == 0, "v3d_gemm: batch strides must keep 16-byte alignment");
     V3D_REQUIRE(a->a_rows > 0 && a->a_row0 >= 0, "v3d_gemm: a_rows (rows addressable behind A) must be given");
+    V3D_REQUIRE(!a->bias || ((uintptr_t)a->bias & 15) == 0, "v3d_gemm: bias must be 16-byte aligned");
     const long long mtiles = (a->M + 127) / 128, ntiles = (a->N + 63) / 64;
     V3D_REQUIRE(mtiles * ntiles < (1ll << 31), "v3d_gemm: grid too large");
     const int taps = a->mode == V3D_GEMM_LINEAR ? 1 : (a->mode == V3D_GEMM_CONV3X3 ? 9 : 3);
-    const unsigned long long a_bytes = (unsigned long long)a->a_rows * a->lda * 2ull;
     const long long ldw = a->ldw ? a->ldw : a->K;
     V3D_REQUIRE(ldw >= a->K && ldw % 8 == 0, "v3d_gemm: ldw must be >= K and a multiple of 8");
+    const unsigned long long a_bytes = (unsigned long long)a->a_rows * a->lda * 2ull;
     const unsigned long long w_bytes = ((unsigned long long)(taps * a->N - 1) * ldw + a->K) * 2ull;
     V3D_REQUIRE(a_bytes <= kMaxBufBytes && w_bytes <= kMaxBufBytes, "v3d_gemm: operand larger than 4 GiB - 256 B (A %llu B, W %llu B)", a_bytes, w_bytes);
     GP p;

@@ -63,14 +63,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
         for (int e = 0; e < 8; ++e) s[j][e] = q[j][e] = 0.f;
 
     if (trow < g.RPP) {
-        for (long long r = r_begin + trow; r < r_end; r += g.RPP) {
-            const long long row = img * S + r;
+        // 4 rows per trip: the 4 (x NV) 16-byte loads are issued back to back so several KB per wave are in flight
+        constexpr int UR = 4;
+        for (long long r = r_begin + trow; r < r_end; r += (long long)UR * g.RPP) {
+            uint4 v[UR][NVMAX];
 #pragma unroll
-            for (int j = 0; j < NVMAX; ++j) {
-                const int v = tcol + j * g.TPR;
-                if (j < g.NV && v < g.VC) {
+            for (int u = 0; u < UR; ++u) {
+                const long long rr = r + (long long)u * g.RPP;
+#pragma unroll
+                for (int j = 0; j < NVMAX; ++j) {
+                    const int vc = tcol + j * g.TPR;
+                    v[u][j] = (rr < r_end && j < g.NV && vc < g.VC) ? load_vec2(x1, C1, x2, C2, img * S + rr, vc * 8) : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+#pragma unroll
+                for (int j = 0; j < NVMAX; ++j) {
                     float f[8];
-                    unpack8(load_vec2(x1, C1, x2, C2, row, v * 8), f);
+                    unpack8(v[u][j], f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         s[j][e] += f[e];
@@ -259,8 +270,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
-inline void gn_grid(long long n_img, long long S, const GNGeom& g, long long& chunks, long long& rpb) {
-    long long want = 4096 / (n_img > 0 ? n_img : 1);
+inline void gn_grid(long long n_img, long long S, const GNGeom& g, long long& chunks, long long& rpb, long long target_blocks = 4096) {
+    long long want = target_blocks / (n_img > 0 ? n_img : 1);
     if (want < 1) want = 1;
     long long maxchunks = (S + g.RPP - 1) / g.RPP;
     chunks = want < maxchunks ? want : maxchunks;
@@ -288,7 +299,7 @@ extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, i
     V3D_REQUIRE(stats != nullptr && imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_stats: bad stats/imgs_per_stat");
     const GNGeom g = gn_geom(C1 + C2);
     long long chunks, rpb;
-    gn_grid(n_img, S, g, chunks, rpb);
+    gn_grid(n_img, S, g, chunks, rpb, 2048);
     hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)chunks, (unsigned)n_img), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x1, (long long)C1, (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups,
                        (long long)imgs_per_stat, rpb);

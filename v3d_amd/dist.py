@@ -73,8 +73,9 @@ class FrameShard:
         else:
             xs = x
         xs = xs.contiguous()
-        buf = torch.empty((self.world,) + tuple(xs.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(buf, xs, group=self.group)
+        buf = torch.empty((self.world * xs.shape[0],) + tuple(xs.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(buf, xs, group=self.group)      # concatenated along dim 0: [world * B, T_max, ...]
+        buf = buf.reshape((self.world,) + tuple(xs.shape))
         return torch.cat([buf[r][:, :len(p)] for r, p in enumerate(self.parts)], dim=1).contiguous()
 
     # ---- (ii) temporal conv halos -------------------------------------------------------------------
