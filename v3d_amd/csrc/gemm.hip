@@ -38,9 +38,12 @@ struct GP {
     long long S;
     long long sA, sW, sO;
     int mt, nt;  // tile counts
+    int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads
 };
 
-__device__ __attribute__((aligned(64))) unsigned int g_zero_page[16] = {0};
+// 64 KiB of zeros: an invalid (padding / tail) lane of the LDS-DMA points here and can still be advanced by k0 like a
+// real row pointer (K * 2 bytes <= 64 KiB is checked on the host), so the main loop has no per-step selects.
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[16384] = {0};
 
 template <int MODE>
 struct RowInfo {};
@@ -116,13 +119,114 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // ---- epilogue shared by both main loops --------------------------------------------------------------------------
 // The wave holds MF x NF fragments; per fragment a lane owns 4 consecutive n (= (lane>>4)*4 + r) of pixel m = lane&15.
+// bf16 outputs are staged through a wave-private LDS region (`stage`, >= MF*16 rows of (WNout*2 + 16) bytes) and leave as
+// 16-byte-per-lane stores covering whole row segments.  Two code paths: a branch-free FAST path for wave tiles that lie
+// completely inside the output (every predicate is wave-uniform: float4 bias / per-image vector loads, 8-byte residual
+// loads, no per-element bounds checks) and the generic path with per-element predicates for ragged M / N edges.
+// (The first version had only the generic path: 1500 VALU + 380 exec-mask branches per wave against 160 MFMAs on the
+// K = 320 GEGLU GEMM, see profiles/r01_gemm_ablation.txt.)
 template <int MF, int NF, bool GEGLU>
-__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane) {
+__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
+                                         unsigned char* stage) {
+    if (p.ablate & 1) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sum == 123.456f) reinterpret_cast<float*>(p.out)[0] = sum;   // keeps the accumulators live
+        return;
+    }
     const long long Nout = GEGLU ? p.N / 2 : p.N;
+    constexpr int NFO = GEGLU ? NF / 2 : NF;          // output fragments per wave-tile row
+    constexpr int SROW = NFO * 32 + 16;               // staging row stride in bytes (16 B pad)
+    const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;   // first output column of this wave tile
+    const bool staged = stage != nullptr && !p.out_fp32 && (p.ldo % 8 == 0) && (ncol0 % 8 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.out) + (size_t)z * p.sO * 2) % 16 == 0);
     const bool vec_ok = (p.ldo % 4 == 0) && (!p.res1 || p.ldr1 % 4 == 0) && (!p.res2 || p.ldr2 % 4 == 0);
+    const bool fast = (mw0 + MF * 16 <= p.M) && (nw0 + NF * 16 <= p.N) && vec_ok && (staged || p.out_fp32) &&
+                      (!p.add || ((reinterpret_cast<uintptr_t>(p.add) % 16 == 0) && (p.add_ld % 4 == 0))) &&
+                      (!p.res1 || reinterpret_cast<uintptr_t>(p.res1) % 8 == 0) && (!p.res2 || reinterpret_cast<uintptr_t>(p.res2) % 8 == 0);
+    const int fr = lane & 15, fq = (lane >> 4) * 4;
+    if (fast) {
+        const int nb = (int)nw0 + fq;                  // this lane's first packed weight row (tile-relative math in 32 bit)
+        float4 bv[NF];
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + nb + j * 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const long long m = mw0 + i * 16 + fr;
+            float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
+            if (p.coef) {
+                const float* cf = p.coef + (m / p.coef_rpg) * 3;
+                ca = cf[0]; c1 = cf[1]; c2 = cf[2];
+            }
+            const float* addv = p.add ? p.add + (m / p.add_rpg) * p.add_ld + nb : nullptr;
+            const bf16_t* r1 = p.res1 ? p.res1 + m * p.ldr1 + (int)ncol0 + fq : nullptr;
+            const bf16_t* r2 = p.res2 ? p.res2 + m * p.ldr2 + (int)ncol0 + fq : nullptr;
+            float* of = p.out_fp32 ? reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + (int)ncol0 + fq : nullptr;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                if (GEGLU && (j & 1)) continue;
+                float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+                if (addv) {
+                    const float4 a = *reinterpret_cast<const float4*>(addv + j * 16);
+                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                }
+                if (GEGLU) {
+                    constexpr int dummy = 0;
+                    const int jg = (j + 1 < NF) ? j + 1 : j;
+                    float g[4] = {acc[i][jg][0] + bv[jg].x, acc[i][jg][1] + bv[jg].y, acc[i][jg][2] + bv[jg].z, acc[i][jg][3] + bv[jg].w};
+                    if (addv) {
+                        const float4 a = *reinterpret_cast<const float4*>(addv + jg * 16);
+                        g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+                    (void)dummy;
+                }
+                const int jo = GEGLU ? (j >> 1) : j;
+                float o[4] = {ca * v[0], ca * v[1], ca * v[2], ca * v[3]};
+                if (r1) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(r1 + jo * 16);
+                    o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
+                }
+                if (r2) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(r2 + jo * 16);
+                    o[0] += c2 * bflo(rr.x); o[1] += c2 * bfhi(rr.x); o[2] += c2 * bflo(rr.y); o[3] += c2 * bfhi(rr.y);
+                }
+                if (of) {
+                    *reinterpret_cast<float4*>(of + jo * 16) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    *reinterpret_cast<uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2) =
+                        make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                }
+            }
+        }
+        if (!p.out_fp32) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int CPRO = NFO * 2;                  // 16-byte chunks per staged row
+            constexpr int ROWS = MF * 16;
+            static_assert((ROWS * CPRO) % 64 == 0, "staged tile must be a whole number of wave-wide stores");
+            bf16_t* outz = reinterpret_cast<bf16_t*>(p.out) + z * p.sO + mw0 * p.ldo + ncol0;
+#pragma unroll
+            for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                const int c = c0 + lane;
+                const int row = c / CPRO, ch = c % CPRO;
+                *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
+            }
+        }
+        return;
+    }
+    // ---------------- generic path (ragged edges) ----------------
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        const long long m = mw0 + i * 16 + (lane & 15);
+        const long long m = mw0 + i * 16 + fr;
         if (m >= p.M) continue;
         float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
         if (p.coef) {
@@ -135,31 +239,18 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
 #pragma unroll
         for (int j = 0; j < NF; j += 1) {
             if (GEGLU && (j & 1)) continue;  // gate fragments are consumed with their value fragment
-            const long long np = nw0 + j * 16 + (lane >> 4) * 4;  // packed weight-row index
+            const long long np = nw0 + j * 16 + fq;  // packed weight-row index
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            if (np + 3 < p.N) {
-                if (p.bias) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + np);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (addv) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += addv[np + r];
-                }
-            } else if (np < p.N) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (np + r < p.N) {
-                        if (p.bias) v[r] += p.bias[np + r];
-                        if (addv) v[r] += addv[np + r];
-                    }
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];
+                if (np + r < p.N) {
+                    if (p.bias) v[r] += p.bias[np + r];
+                    if (addv) v[r] += addv[np + r];
                 }
             }
             long long col = np;
             if (GEGLU) {
-                // j even = value rows, j+1 = the matching gate rows (same lane, same r)
                 const int jg = (j + 1 < NF) ? j + 1 : j;
                 const long long ng = np + 16;
 #pragma unroll
@@ -174,47 +265,16 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                 col = (np >> 5) * 16 + (np & 15);
             }
             if (col >= Nout) continue;
-            const bool full = vec_ok && (col + 3 < Nout);
-            float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = ca * v[r];
-            if (p.res1) {
-                if (full) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res1 + m * p.ldr1 + col);
-                    o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col + r < Nout) o[r] += c1 * bf2f(p.res1[m * p.ldr1 + col + r]);
-                }
-            }
-            if (p.res2) {
-                if (full) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res2 + m * p.ldr2 + col);
-                    o[0] += c2 * bflo(rr.x); o[1] += c2 * bfhi(rr.x); o[2] += c2 * bflo(rr.y); o[3] += c2 * bfhi(rr.y);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col + r < Nout) o[r] += c2 * bf2f(p.res2[m * p.ldr2 + col + r]);
-                }
-            }
-            if (p.out_fp32) {
-                float* op = reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + col;
-                if (full) {
-                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col + r < Nout) op[r] = o[r];
-                }
-            } else {
-                bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + z * p.sO + m * p.ldo + col;
-                if (full) {
-                    *reinterpret_cast<uint2*>(op) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col + r < Nout) op[r] = f2bf(o[r]);
+            for (int r = 0; r < 4; ++r) {
+                if (col + r < Nout) {
+                    float o = ca * v[r];
+                    if (p.res1) o += c1 * bf2f(p.res1[m * p.ldr1 + col + r]);
+                    if (p.res2) o += c2 * bf2f(p.res2[m * p.ldr2 + col + r]);
+                    if (p.out_fp32)
+                        (reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + col)[r] = o;
+                    else
+                        (reinterpret_cast<bf16_t*>(p.out) + z * p.sO + m * p.ldo + col)[r] = f2bf(o);
                 }
             }
         }
@@ -281,46 +341,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
     RowInfo<MODE> ri[APW];
 #pragma unroll
     for (int i = 0; i < APW; ++i) ri[i].init(p, m0 + (wave + NW * i) * RPP + prow);
-    const bf16_t* arow[APW];   // source row pointer (+ k-chunk) for the current tap, or nullptr (-> zero page)
+    const bf16_t* arow[APW];   // source row pointer (+ k-chunk) for the current tap; invalid rows point into the zero page
     const bf16_t* brow[BPW];
     auto set_tap = [&](int tap) {
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             long long s;
             const bool ok = ri[i].tap(p, tap, s);
-            arow[i] = ok ? A + (s + p.a_row0) * p.lda + kchunk_a[i] * 8 : nullptr;
+            arow[i] = (ok ? A + (s + p.a_row0) * p.lda : zero) + kchunk_a[i] * 8;
         }
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             const long long n = n0 + (wave + NW * i) * RPP + prow;
-            brow[i] = (n < p.N) ? W + ((long long)tap * p.N + n) * p.ldw + kchunk_b[i] * 8 : nullptr;
+            brow[i] = ((n < p.N) ? W + ((long long)tap * p.N + n) * p.ldw : zero) + kchunk_b[i] * 8;
         }
     };
-    const int ksteps = (int)((p.K + BK2 - 1) / BK2);
+    const int ksteps = (int)(p.K / BK2);                 // host guarantees K % BK2 == 0 for this kernel
     const int nsteps = ksteps * ntaps<MODE>();
-    int ld_tap = 0, ld_k0 = 0, ld_step = 0;
+    int ld_tap = 0, ld_k0 = 0;
     set_tap(0);
+    // steps issued past the end of the contraction (ring tail) re-read valid rows of the last tap: harmless dummies that
+    // keep the per-wave DMA count per stage constant for the counted vmcnt waits
     auto issue = [&](int stage) {
-        const bool live = ld_step < nsteps;
         unsigned char* sbase = lds + stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const bool kok = live && (ld_k0 + kchunk_a[i] * 8 < p.K);
-            const bf16_t* g = (kok && arow[i]) ? arow[i] + ld_k0 : zero;
-            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sbase + (wave + NW * i) * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < APW; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(arow[i] + ld_k0), (__attribute__((address_space(3))) void*)(sbase + (wave + NW * i) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BPW; ++i) {
-            const bool kok = live && (ld_k0 + kchunk_b[i] * 8 < p.K);
-            const bf16_t* g = (kok && brow[i]) ? brow[i] + ld_k0 : zero;
-            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sbase + BM * ROWB + (wave + NW * i) * 1024), 16, 0, 0);
-        }
-        ++ld_step;
+        for (int i = 0; i < BPW; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(brow[i] + ld_k0), (__attribute__((address_space(3))) void*)(sbase + BM * ROWB + (wave + NW * i) * 1024), 16, 0, 0);
         ld_k0 += BK2;
         if (ld_k0 >= p.K) {
             ld_k0 = 0;
-            ++ld_tap;
-            if (ntaps<MODE>() > 1 && ld_tap < ntaps<MODE>()) set_tap(ld_tap);
+            if (ntaps<MODE>() > 1 && ++ld_tap < ntaps<MODE>()) set_tap(ld_tap);
         }
     };
 
@@ -361,9 +414,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (dummy) tail DMAs before LDS is released
-
-    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (dummy) tail DMAs before the ring is reused / released
+    __builtin_amdgcn_s_barrier();                      // every wave has finished reading the last stage
+    asm volatile("" ::: "memory");
+    constexpr int NFO_ = GEGLU ? NF / 2 : NF;
+    constexpr int STAGE_REGION = MF * 16 * (NFO_ * 32 + 16);
+    constexpr bool CAN_STAGE = NW * STAGE_REGION <= NS * STAGE_BYTES;   // else: direct MFMA-layout stores
+    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, CAN_STAGE ? lds + wave * STAGE_REGION : nullptr);
 }
 
 // =====================================================================================================================
@@ -468,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
         if (step + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
-    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, nullptr);
 }
 
 int impl_choice() {
@@ -495,7 +552,8 @@ int launch(const GP& p0, int batch, hipStream_t st) {
     p.mt = (int)((p.M + BM - 1) / BM);
     p.nt = (int)((p.N + BN - 1) / BN);
     dim3 grid((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
-    if (impl_choice() == 1) {
+    if (impl_choice() == 1 || p.K % 32 != 0 || p.K * 2 > 65536) {
+        // v1 also serves ragged contractions (K % 32 != 0: the 8-channel input conv, odd test shapes)
         hipLaunchKernelGGL((gemm_kernel_v1<BM, BN, MODE, GEGLU>), grid, dim3(256), 0, st, p);
         return v3d_check_launch("v3d_gemm");
     }
@@ -507,6 +565,7 @@ int launch(const GP& p0, int batch, hipStream_t st) {
         const long long stages32 = (long long)ntaps<MODE>() * ((p.K + 31) / 32);
         cfg = stages32 <= 40 ? 2 : 1;
     }
+    if (p.K % 64 != 0 && (cfg == 1 || cfg == 4)) cfg = (cfg == 1) ? 0 : 3;   // BK 64 stages need K % 64 == 0
     switch (cfg) {
         case 1:   // BK 64 stages, 2 deep (one in flight)
             hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), grid, dim3(256), 0, st, p);
@@ -533,7 +592,21 @@ int launch(const GP& p0, int batch, hipStream_t st) {
 }
 
 template <int MODE, bool GEGLU>
+int launch256(const GP& p0, int batch, hipStream_t st, int cfg) {
+    GP p = p0;
+    p.mt = (int)((p.M + 255) / 256);
+    p.nt = (int)((p.N + 255) / 256);
+    dim3 grid((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
+    if (cfg == 5)
+        hipLaunchKernelGGL((gemm_kernel_v2<256, 256, 4, 2, 3, 1, MODE, GEGLU>), grid, dim3(512), 0, st, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel_v2<256, 256, 4, 2, 2, 2, MODE, GEGLU>), grid, dim3(512), 0, st, p);
+    return v3d_check_launch("v3d_gemm");
+}
+
+template <int MODE, bool GEGLU>
 int dispatch(const GP& p, int batch, hipStream_t st) {
+    if ((cfg_choice() == 5 || cfg_choice() == 6) && impl_choice() != 1 && p.N % 256 == 0 && p.K % 64 == 0 && p.K * 2 <= 65536) return launch256<MODE, GEGLU>(p, batch, st, cfg_choice());
     // N tile: 128 unless a 64-wide tile wastes less (e.g. N = 320: 5 x 64 exact vs 3 x 128 = 17 % padding)
     const long long w128 = ((p.N + 127) / 128) * 128, w64 = ((p.N + 63) / 64) * 64;
     if (w64 < w128) return launch<128, 64, MODE, GEGLU>(p, batch, st);
@@ -577,6 +650,7 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     p.T = a->T; p.tmin = a->tmin; p.tmax = a->tmax; p.S = a->S;
     p.sA = a->sA; p.sW = a->sW; p.sO = a->sO;
     p.mt = p.nt = 0;
+    { static int ab = -1; if (ab < 0) { const char* e = getenv("V3D_GEMM_ABLATE"); ab = e ? atoi(e) : 0; } p.ablate = ab; }
     hipStream_t st = (hipStream_t)stream;
     switch (a->mode) {
         case V3D_GEMM_LINEAR:
