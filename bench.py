@@ -122,16 +122,25 @@ def cpu_baseline(unet, dec, budget_s=40.0):
     ctx = torch.randn(n, 1, 1024, generator=g)
     y = torch.randn(n, 768, generator=g)
     t0 = time.time()
-    O.unet_forward(sd, synth.unet_config(320), x8, ts, ctx, y, Tb, torch.zeros(2, Tb))
+    ref = O.unet_forward(sd, synth.unet_config(320), x8, ts, ctx, y, Tb, torch.zeros(2, Tb))
     t_unet = time.time() - t0
     del sd
+    # full-width parity spot check on the same inputs: HIP engine (bf16) vs the fp32 oracle
+    dev = next(unet.parameters()).device
+    got = unet(x8.to(dev), ts.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=Tb, image_only_indicator=torch.zeros(2, Tb, device=dev))
+    cos_unet = torch.nn.functional.cosine_similarity(got.float().cpu().flatten(), ref.flatten(), dim=0).item()
+    rel_unet = ((got.float().cpu() - ref).abs().max() / ref.abs().max()).item()
     dsd = {k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
     z = torch.randn(Tb, 4, LAT, LAT, generator=g)
     t0 = time.time()
-    O.decoder_forward(dsd, synth.decoder_config(128), z, Tb)
+    dref = O.decoder_forward(dsd, synth.decoder_config(128), z, Tb)
     t_vae = time.time() - t0
+    dgot = dec(z.to(dev), timesteps=Tb)
+    cos_vae = torch.nn.functional.cosine_similarity(dgot.float().cpu().flatten(), dref.flatten(), dim=0).item()
     t_sample = STEPS * t_unet * (2 * T_FRAMES / n) + t_vae * (T_FRAMES / Tb)
     return {"value": round(T_FRAMES / t_sample, 6), "unit": "frames/s", "cores": cores, "kind": "port",
+            "parity_full_width": {"unet_eval_cosine": round(cos_unet, 6), "unet_eval_max_rel_err": round(rel_unet, 5),
+                                  "vae_decode_cosine": round(cos_vae, 6), "note": "HIP bf16 engine vs fp32 CPU oracle on the timed sample's inputs"},
             "sample": f"fp32 oracle: 1 U-Net eval on {n}/36 images ({t_unet:.1f} s) + decode of {Tb}/18 frames ({t_vae:.1f} s), "
                       f"extrapolated to 25 evals x 36 images + 18 frames = {t_sample:.0f} s/sample"}
 

@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 #define V3D_ABI_VERSION 1
+#define V3D_GN_SLOTS 32
 
 typedef void* v3d_stream_t; /* hipStream_t */
 
@@ -96,7 +97,8 @@ int v3d_sizeof_gemm_args(void);
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (32 groups) over channels-last activations, optionally over two channel-concatenated sources
  * (the U-Net skip concat th.cat([h, hs.pop()], 1) at video_model.py:483 is never materialised).
- *   stats[g_img][group][2] += (sum, sumsq) over rows of the images in that stat group  (fp32 atomics; caller zeroes)
+ *   stats[g_img][slot][group][2] += (sum, sumsq) over rows of the images in that stat group  (fp32 atomics; caller
+ *   zeroes; V3D_GN_SLOTS partial-sum slots per group spread the atomics, consumers add the slots up)
  *   imgs_per_stat = 1 for 2-D GroupNorm, = frames-per-sample for the 3-D GroupNorm whose statistics span
  *   all frames (openaimodel.py:267-271,302-305 with dims=3).  Under frame sharding the caller all-reduces `stats`.
  *   apply: y = (x - mean) * rstd * gamma + beta, mean/var from stats and `count` (elements per group, global),

@@ -98,14 +98,15 @@ class EmulOps(OpsBase):
         x = self._cat(x1, x2).float()
         C = x.shape[-1]
         xg = x.reshape(n_img // imgs_per_stat, imgs_per_stat * S, groups, C // groups)
-        stats[..., 0] += xg.sum(dim=(1, 3))
-        stats[..., 1] += (xg * xg).sum(dim=(1, 3))
+        stats[:, 0, :, 0] += xg.sum(dim=(1, 3))          # [stat group][slot][group][2]; the emulator uses slot 0 only
+        stats[:, 0, :, 1] += (xg * xg).sum(dim=(1, 3))
 
     def groupnorm_apply(self, x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu):
         x = self._cat(x1, x2).float()
         C = x.shape[-1]
-        mean = stats[..., 0] / count
-        var = (stats[..., 1] / count - mean * mean).clamp_min(0)
+        tot = stats.sum(dim=1)
+        mean = tot[..., 0] / count
+        var = (tot[..., 1] / count - mean * mean).clamp_min(0)
         rstd = torch.rsqrt(var + eps)
         xg = x.reshape(n_img // imgs_per_stat, imgs_per_stat * S, groups, C // groups)
         y = (xg - mean[:, None, :, None]) * rstd[:, None, :, None]

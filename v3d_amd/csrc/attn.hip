@@ -1,4 +1,6 @@
 // Attention kernels for gfx950: spatial (streamed-softmax MFMA, d_head 64) and temporal (T <= 32 frames).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -159,6 +161,217 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Spatial self-attention v2 (default).  Same mathematics and the same operand trick as v1 (S^T = K.Q^T so that a lane
+// owns a query column; the P.V contraction index is a key permutation applied identically to V^T), plus:
+//   * K / V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-deep ring, counted vmcnt, one barrier per tile;
+//   * 128-byte LDS rows with the 16-byte chunk position XOR-swizzled by (row >> 1) & 7 (on the DMA source address):
+//     every ds_read_b128 group of the K and the V^T fragment reads hits 16 distinct slots;
+//   * the K rows are assigned to MFMA rows through pi(8A + 4h + c) = 16(A>>1) + 8h + 4(A&1) + c, which makes the 8 P
+//     values a lane feeds into one P.V k-step 8 CONTIGUOUS keys -> V^T fragments are single ds_read_b128;
+//   * QG query groups of 32 per wave share every K / V^T fragment read (QG = 2 for long sequences);
+//   * one softmax update per 64-key tile (not per 32), O rescale skipped when no running max moved in the wave.
+// ------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) unsigned int g_attn_zero[64] = {0};
+
+template <int QG>
+__global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* __restrict__ q, long long ldq,
+                                                                 const bf16_t* __restrict__ k, long long ldk,
+                                                                 const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
+                                                                 long long ldo, long long S, int heads, float scale2) {
+    constexpr int NS = 3;
+    constexpr int TILE_BYTES = 2 * 64 * 128;   // K tile (64 keys x 128 B) + V^T tile (64 d-rows x 128 B)
+    constexpr int PIECES = 4;                  // per wave per tile: 2 K pieces + 2 V pieces (8 rows x 128 B each)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, hi = lane >> 5;
+    const long long n = blockIdx.z;
+    const int h = blockIdx.y;
+    const long long C = (long long)heads * 64;
+    const long long qbase = (long long)blockIdx.x * (128 * QG) + wave * (32 * QG);
+
+    const bufrsrc_t rsQ = make_rsrc(q + n * S * ldq + h * 64, (unsigned)(((S - 1) * ldq + 64) * 2));
+    bf16x8 qf[QG][4];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const long long qrow = qbase + g * 32 + qi;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            qf[g][st] = __builtin_bit_cast(bf16x8, buf_load16(rsQ, qrow < S ? (unsigned)((qrow * ldq + hi * 8 + st * 16) * 2) : kInvalid));
+    }
+
+    // ---- LDS-DMA sources: piece = 8 rows x 128 B; lane l -> row (l >> 3), chunk position (l & 7), logical chunk pos ^ swz
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero);
+    const int prow = lane >> 3;
+    const bf16_t* kbase = k + n * S * ldk + h * 64;
+    const bf16_t* vbase = vT + (n * C + h * 64) * S;
+    int krow[2], vrow[2], kch[2], vch[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        krow[i] = (wave * 2 + i) * 8 + prow;          // key row within the tile / d row of V^T
+        vrow[i] = krow[i];
+        kch[i] = (lane & 7) ^ ((krow[i] >> 1) & 7);
+        vch[i] = kch[i];
+    }
+    const int ntiles = (int)((S + 63) / 64);
+    int ld_tile = 0;
+    auto issue = [&](int stage) {
+        unsigned char* sb = lds + stage * TILE_BYTES;
+        const long long k0 = (long long)ld_tile * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = ld_tile < ntiles && (k0 + krow[i]) < S;
+            const bf16_t* g = ok ? kbase + (k0 + krow[i]) * ldk + kch[i] * 8 : zero;
+            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sb + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = ld_tile < ntiles && (k0 + vch[i] * 8) < S;
+            const bf16_t* g = ok ? vbase + (long long)vrow[i] * S + k0 + vch[i] * 8 : zero;
+            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sb + 8192 + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+        ++ld_tile;
+    };
+
+    // fragment read offsets.  K: MFMA row i = qi holds key pi(i); logical chunk = 2*st + hi.
+    const int A_ = qi >> 3, hh = (qi >> 2) & 1, cc = qi & 3;
+    const int kkey = 16 * (A_ >> 1) + 8 * hh + 4 * (A_ & 1) + cc;                 // pi(qi)
+    int koff[2][4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int row = sub * 32 + kkey;
+            koff[sub][st] = row * 128 + (((2 * st + hi) ^ ((row >> 1) & 7)) * 16);
+        }
+    // V^T: row d = db*32 + qi, logical chunk = sub*4 + ks*2 + hi (8 contiguous keys)
+    int voff[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) voff[db] = 8192 + (db * 32 + qi) * 128;
+    const int vsw = (qi >> 1) & 7;     // (row >> 1) & 7 with row = db*32 + qi  (db*32 >> 1 is a multiple of 8)
+
+    f32x16 o[QG][2];
+    float m_run[QG], l_run[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[g][0][r] = o[g][1][r] = 0.f;
+        m_run[g] = -INFINITY;
+        l_run[g] = 0.f;
+    }
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (NS - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue((t + NS - 1) % NS);
+        const unsigned char* sb = lds + (t % NS) * TILE_BYTES;
+        const long long k0 = (long long)t * 64;
+        const bool tail = (k0 + 64 > S);
+
+        // ---- S^T = K . Q^T for both 32-key halves ----
+        f32x16 sT[QG][2];
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sT[g][sub][r] = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + koff[sub][st]);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) sT[g][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[g][st], sT[g][sub], 0, 0, 0);
+            }
+        // sT[g][sub][r] = score(key = k0 + sub*32 + 16*(r>>3) + 8*hi + (r&7), query qbase + g*32 + qi)
+        bf16x8 pf[QG][2][2];
+        bool any_rescale = false;
+        float alpha[QG];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sc = sT[g][sub][r] * scale2;
+                    if (tail && (k0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7)) >= S) sc = -INFINITY;
+                    sT[g][sub][r] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[g], mx);
+            alpha[g] = (m_new == -INFINITY) ? 1.f : exp2f(m_run[g] - m_new);
+            any_rescale |= (alpha[g] != 1.f);
+            float psum = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = (m_new == -INFINITY) ? 0.f : exp2f(sT[g][sub][r] - m_new);
+                    psum += pv[r];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x4 u = {pack2bf(pv[ks * 8 + 0], pv[ks * 8 + 1]), pack2bf(pv[ks * 8 + 2], pv[ks * 8 + 3]),
+                                     pack2bf(pv[ks * 8 + 4], pv[ks * 8 + 5]), pack2bf(pv[ks * 8 + 6], pv[ks * 8 + 7])};
+                    pf[g][sub][ks] = __builtin_bit_cast(bf16x8, u);
+                }
+            }
+            l_run[g] = l_run[g] * alpha[g] + psum;
+            m_run[g] = m_new;
+        }
+        if (__any(any_rescale)) {
+#pragma unroll
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[g][0][r] *= alpha[g];
+                    o[g][1][r] *= alpha[g];
+                }
+        }
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = ((sub * 4 + ks * 2 + hi) ^ vsw) * 16;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + voff[db] + ch);
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) o[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][sub][ks], o[g][db], 0, 0, 0);
+                }
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const long long qrow = qbase + g * 32 + qi;
+        const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (qrow < S) {
+            bf16_t* op = out + (n * S + qrow) * ldo + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int d0 = db * 32 + 8 * gg + 4 * hi;
+                    *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(o[g][db][gg * 4 + 0] * inv, o[g][db][gg * 4 + 1] * inv),
+                                                                    pack2bf(o[g][db][gg * 4 + 2] * inv, o[g][db][gg * 4 + 3] * inv));
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Temporal self-attention (frame axis).  A "problem" is one (sample b, position s, head h): Tq x Tk scores,
 // d_head 64.  G = 64 / Tq problems share a wave; lane (slot, i) owns query frame i of its slot's problem, keeps
 // q and the output row in registers and walks the Tk keys/values staged in LDS (all lanes of a slot read the same
@@ -281,10 +494,25 @@ extern "C" int v3d_attn_spatial(const void* q, int64_t ldq, const void* k, int64
     V3D_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "v3d_attn_spatial: ldq/ldk must be multiples of 8, ldo of 4");
     V3D_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vT) & 15) == 0 && ((uintptr_t)out & 7) == 0, "v3d_attn_spatial: misaligned pointer");
     V3D_REQUIRE((unsigned long long)S * (ldq > ldk ? ldq : ldk) * 2ull <= kMaxBufBytes, "v3d_attn_spatial: per-image q/k slab exceeds 4 GiB");
-    dim3 grid((unsigned)((S + 127) / 128), (unsigned)heads, (unsigned)n_img);
-    hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (long long)ldq,
-                       (const bf16_t*)k, (long long)ldk, (const bf16_t*)vT, (bf16_t*)out, (long long)ldo, (long long)S, heads,
-                       scale * 1.44269504088896340736f);
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("V3D_ATTN_IMPL");
+        impl = e ? atoi(e) : 2;
+    }
+    const float sc2 = scale * 1.44269504088896340736f;
+    if (impl == 1) {
+        dim3 grid((unsigned)((S + 127) / 128), (unsigned)heads, (unsigned)n_img);
+        hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (long long)ldq,
+                           (const bf16_t*)k, (long long)ldk, (const bf16_t*)vT, (bf16_t*)out, (long long)ldo, (long long)S, heads, sc2);
+    } else if (S >= 1024 && impl != 3) {
+        dim3 grid((unsigned)((S + 255) / 256), (unsigned)heads, (unsigned)n_img);
+        hipLaunchKernelGGL(attn_spatial_v2_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (long long)ldq,
+                           (const bf16_t*)k, (long long)ldk, (const bf16_t*)vT, (bf16_t*)out, (long long)ldo, (long long)S, heads, sc2);
+    } else {
+        dim3 grid((unsigned)((S + 127) / 128), (unsigned)heads, (unsigned)n_img);
+        hipLaunchKernelGGL(attn_spatial_v2_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (long long)ldq,
+                           (const bf16_t*)k, (long long)ldk, (const bf16_t*)vT, (bf16_t*)out, (long long)ldo, (long long)S, heads, sc2);
+    }
     return v3d_check_launch("v3d_attn_spatial");
 }
 

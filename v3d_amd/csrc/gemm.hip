@@ -564,8 +564,11 @@ int launch(const GP& p0, int batch, hipStream_t st) {
         // BK 32, 48 KiB LDS, 3 blocks/CU) wins; long ones prefer fewer barriers per MFMA (2 stages of BK 64).
         const long long stages32 = (long long)ntaps<MODE>() * ((p.K + 31) / 32);
         cfg = stages32 <= 40 ? 2 : 1;
+        // 64-wide N tiles (N = 320 and friends): a 256 x 64 tile with the 4 waves stacked along M doubles the MFMAs per
+        // barrier and halves the weight re-reads (lin_L0_320x320 433 -> 487, convt_L0_320 568 -> 734 TF/s)
+        if (BN == 64) cfg = (p.K % 64 == 0) ? 9 : 8;
     }
-    if (p.K % 64 != 0 && (cfg == 1 || cfg == 4)) cfg = (cfg == 1) ? 0 : 3;   // BK 64 stages need K % 64 == 0
+    if (p.K % 64 != 0 && (cfg == 1 || cfg == 4 || cfg == 7 || cfg == 9)) cfg = (cfg == 4) ? 3 : (cfg == 9 ? 8 : 0);   // BK 64 stages need K % 64 == 0
     switch (cfg) {
         case 1:   // BK 64 stages, 2 deep (one in flight)
             hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), grid, dim3(256), 0, st, p);
@@ -582,6 +585,21 @@ int launch(const GP& p0, int batch, hipStream_t st) {
                     hipLaunchKernelGGL((gemm_kernel_v2<256, BN, 4, 2, 4, 1, MODE, GEGLU>), g2, dim3(512), 0, st, p);
                 else
                     hipLaunchKernelGGL((gemm_kernel_v2<256, BN, 4, 2, 3, 2, MODE, GEGLU>), g2, dim3(512), 0, st, p);
+                break;
+            }
+            [[fallthrough]];
+        case 7:   // BK 64 stages, 3 deep
+            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 3, 2, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            break;
+        case 8:   // 256 x 64 tile, 4 waves stacked along M (wave tile 64 x 64), BK 32 x 3
+        case 9:   // 256 x 64 tile, 4 waves, BK 64 x 2
+            if constexpr (BN == 64) {
+                p.mt = (int)((p.M + 255) / 256);
+                dim3 g2((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
+                if (cfg == 8)
+                    hipLaunchKernelGGL((gemm_kernel_v2<256, 64, 4, 1, 3, 1, MODE, GEGLU>), g2, dim3(256), 0, st, p);
+                else
+                    hipLaunchKernelGGL((gemm_kernel_v2<256, 64, 4, 1, 2, 2, MODE, GEGLU>), g2, dim3(256), 0, st, p);
                 break;
             }
             [[fallthrough]];

@@ -4,6 +4,7 @@
 
 namespace {
 
+constexpr int SLOTS = V3D_GN_SLOTS;   // partial-sum slots per statistics group (spreads the fp32 atomics)
 constexpr int NVMAX = 2;       // vector columns per thread -> supports C <= 2*256*8 = 4096
 constexpr int CMAX = 4096;
 
@@ -110,7 +111,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
             a += sh_s[c];
             b += sh_q[c];
         }
-        float* dst = stats + ((img / imgs_per_stat) * groups + tid) * 2;
+        // slot = row-chunk index modulo SLOTS: a 3-D GroupNorm reduces T x chunks blocks into the same group, and
+        // ~1000 same-address atomics serialised in the first version (profiles/r01b_kernel_stats_v2.txt)
+        const int slot = (int)((blockIdx.x + img * 7) % SLOTS);
+        float* dst = stats + (((img / imgs_per_stat) * SLOTS + slot) * groups + tid) * 2;
         atomicAdd(dst, a);
         atomicAdd(dst + 1, b);
     }
@@ -132,9 +136,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     if (r_end > S) r_end = S;
     const int trow = tid / g.TPR;
     const int tcol = tid - trow * g.TPR;
-    if (trow >= g.RPP) return;
     const int cpg = (int)(C / groups);
-    const float* st = stats + (img / imgs_per_stat) * groups * 2;
+    // combine the SLOTS partial sums of this image's statistics group once per block
+    __shared__ float st[2 * 256];
+    if (tid < groups) {
+        const float* sp = stats + ((img / imgs_per_stat) * SLOTS * groups + tid) * 2;
+        float a = 0.f, b = 0.f;
+#pragma unroll 8
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            a += sp[sl * groups * 2];
+            b += sp[sl * groups * 2 + 1];
+        }
+        st[tid * 2] = a;
+        st[tid * 2 + 1] = b;
+    }
+    __syncthreads();
+    if (trow >= g.RPP) return;
 
     float sc[NVMAX][8], sf[NVMAX][8];
 #pragma unroll

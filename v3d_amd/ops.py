@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 GEMM_LINEAR, GEMM_CONV3X3, GEMM_CONVT3 = 0, 1, 2
+GN_SLOTS = 32   # V3D_GN_SLOTS: partial-sum slots per GroupNorm statistics group
 
 
 @dataclasses.dataclass
@@ -119,7 +120,7 @@ class OpsBase:
         count_imgs = number of images (global) contributing to one statistics group.
         """
         C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
-        stats = self.zeros((n_img // imgs_per_stat, groups, 2), torch.float32, x1.device)
+        stats = self.zeros((n_img // imgs_per_stat, GN_SLOTS, groups, 2), torch.float32, x1.device)
         self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
         if stats_hook is not None:
             stats = stats_hook(stats)
