@@ -567,6 +567,9 @@ int launch(const GP& p0, int batch, hipStream_t st) {
         // 64-wide N tiles (N = 320 and friends): a 256 x 64 tile with the 4 waves stacked along M doubles the MFMAs per
         // barrier and halves the weight re-reads (lin_L0_320x320 433 -> 487, convt_L0_320 568 -> 734 TF/s)
         if (BN == 64) cfg = (p.K % 64 == 0) ? 9 : 8;
+        // wide GEGLU projections at K >= 640 and the 128-channel VAE convs: 256 x 128 tile on 4 waves (wave tile 128 x 64,
+        // 32 MFMAs per barrier, 25 % fewer LDS-fill bytes per flop): lin_L1_ff1_geglu 662 -> 779, lin_L2_ff1_geglu 708 -> 865
+        if (BN == 128 && ((GEGLU && p.K >= 640) || (MODE == V3D_GEMM_CONV3X3 && p.K <= 128)) && p.M >= 4096) cfg = 11;
     }
     if (p.K % 64 != 0 && (cfg == 1 || cfg == 4 || cfg == 7 || cfg == 9)) cfg = (cfg == 4) ? 3 : (cfg == 9 ? 8 : 0);   // BK 64 stages need K % 64 == 0
     switch (cfg) {
@@ -588,6 +591,17 @@ int launch(const GP& p0, int batch, hipStream_t st) {
                 break;
             }
             [[fallthrough]];
+        case 11:  // 256 x 128 tile on 4 waves (wave tile 128 x 64, 32 MFMAs per barrier), BK 32 x 3: 72 KiB -> 2 blocks / CU
+            if constexpr (BN == 128) {
+                p.mt = (int)((p.M + 255) / 256);
+                dim3 g2((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
+                hipLaunchKernelGGL((gemm_kernel_v2<256, 128, 2, 2, 3, 1, MODE, GEGLU>), g2, dim3(256), 0, st, p);
+                break;
+            }
+            [[fallthrough]];
+        case 10:  // BK 32 stages, 2 deep: 32 KiB LDS -> 4 blocks / CU (VGPR-limited)
+            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 1, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            break;
         case 7:   // BK 64 stages, 3 deep
             hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 3, 2, MODE, GEGLU>), grid, dim3(256), 0, st, p);
             break;
