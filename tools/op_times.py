@@ -1,0 +1,47 @@
+"""Per-op timing inside one full-size VideoUNet evaluation: every primitive launch with its shape (HIP events)."""
+import os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from v3d_amd import synth
+from v3d_amd.ops import get_ops
+torch.set_grad_enabled(False)
+dev = "cuda"
+import bench
+unet, wrapped, dec, sampler, denoiser = bench.build_models(dev)
+noise, c, uc = synth.synthetic_conditioning(18, 64, 64, seed=23, device=dev)
+ops = get_ops()
+rec = []
+def wrap(name, keyfn):
+    orig = getattr(ops, name)
+    def f(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = orig(*a, **k); e1.record()
+        rec.append((keyfn(*a, **k), e0, e1))
+        return r
+    setattr(ops, name, f)
+def gk(g):
+    taps = {0: 1, 1: 9, 2: 3}[g.mode]
+    ep = ("G" if g.geglu else "") + ("b" if g.bias is not None else "") + ("a" if g.add is not None else "") + ("r" if g.res1 is not None else "") + ("R" if g.res2 is not None else "") + ("c" if g.coef is not None else "") + ("f" if g.out.dtype == torch.float32 else "")
+    return f"gemm m{g.mode} M={g.M} N={g.N} K={g.K} b={g.batch} [{ep}]", 2.0 * g.M * g.N * g.K * taps * g.batch
+wrap("gemm", gk)
+wrap("groupnorm_stats", lambda x1, x2, st, n, S, g, ips: (f"gn_stats n={n} S={S} C={x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)} ips={ips}", 0))
+wrap("groupnorm_apply", lambda x1, x2, *a: (f"gn_apply rows={x1.shape[0]} C={x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)}", 0))
+wrap("layernorm", lambda x, *a, **k: (f"ln rows={x.shape[0]} C={x.shape[-1]} add={'add' in k}", 0))
+wrap("attn_spatial", lambda q, k, vT, out, n, S, h, sc: (f"attn_spatial n={n} S={S} h={h}", 4.0 * n * h * S * S * 64))
+wrap("attn_temporal", lambda q, k, v, out, h, sc: (f"attn_temporal {tuple(q.shape)}", 0))
+x = torch.cat([noise, noise]); sig = torch.full((36,), 10.0, device=dev)
+cond = {k: torch.cat([uc[k], c[k]]) for k in c}
+extra = {"image_only_indicator": torch.zeros(2, 18, device=dev), "num_video_frames": 18}
+for it in range(2):
+    rec.clear()
+    denoiser(wrapped, x, sig, cond, **extra)
+    torch.cuda.synchronize()
+agg = collections.OrderedDict()
+for (k, fl), a, b in rec:
+    d = agg.setdefault(k, [0, 0.0, 0.0]); d[0] += 1; d[1] += a.elapsed_time(b); d[2] += fl
+tot = sum(v[1] for v in agg.values())
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    tf = f"{v[2] / v[1] / 1e9:7.0f} TF/s" if v[2] else ""
+    print(f"{v[1]:8.3f} ms {v[1] / tot * 100:5.1f}% n={v[0]:3d} avg={v[1] / v[0] * 1e3:8.1f}us {tf}  {k}")
+print(f"total {tot:.2f} ms over {len(rec)} launches")

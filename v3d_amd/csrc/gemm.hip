@@ -125,7 +125,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // loads, no per-element bounds checks) and the generic path with per-element predicates for ragged M / N edges.
 // (The first version had only the generic path: 1500 VALU + 380 exec-mask branches per wave against 160 MFMAs on the
 // K = 320 GEGLU GEMM, see profiles/r01_gemm_ablation.txt.)
-template <int MF, int NF, bool GEGLU>
+template <int MF, int NF, bool GEGLU, bool CAN_STAGE>
 __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
                                          unsigned char* stage) {
     if (p.ablate & 1) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
     constexpr int NFO = GEGLU ? NF / 2 : NF;          // output fragments per wave-tile row
     constexpr int SROW = NFO * 32 + 16;               // staging row stride in bytes (16 B pad)
     const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;   // first output column of this wave tile
-    const bool staged = stage != nullptr && !p.out_fp32 && (p.ldo % 8 == 0) && (ncol0 % 8 == 0) &&
+    const bool staged = CAN_STAGE && !p.out_fp32 && (p.ldo % 8 == 0) && (ncol0 % 8 == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.out) + (size_t)z * p.sO * 2) % 16 == 0);
     const bool vec_ok = (p.ldo % 4 == 0) && (!p.res1 || p.ldr1 % 4 == 0) && (!p.res2 || p.ldr2 % 4 == 0);
     const bool fast = (mw0 + MF * 16 <= p.M) && (nw0 + NF * 16 <= p.N) && vec_ok && (staged || p.out_fp32) &&
@@ -150,6 +150,28 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
     const int fr = lane & 15, fq = (lane >> 4) * 4;
     if (fast) {
         const int nb = (int)nw0 + fq;                  // this lane's first packed weight row (tile-relative math in 32 bit)
+        constexpr int CPRO = NFO * 2;                  // 16-byte chunks per staged row
+        constexpr int ROWS = MF * 16;
+        static_assert((ROWS * CPRO) % 64 == 0, "staged tile must be a whole number of wave-wide stores");
+        // residual #1 comes in through the staging buffer: coalesced 16-byte row loads -> LDS, then each lane picks its 8 bytes in
+        // MFMA layout (the direct 8-byte-per-lane residual loads touched 16 rows per instruction: 129 us vs 70 us for the
+        // attention out-projection at 64x64, profiles/r01d_op_times_unet_eval.txt)
+        const bool res1_lds = CAN_STAGE && p.res1 && !p.out_fp32 && (p.ldr1 % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res1) % 16 == 0);
+        if (CAN_STAGE && res1_lds) {
+            const bf16_t* rz = p.res1 + mw0 * p.ldr1 + ncol0;
+            uint4 rv[ROWS * CPRO / 64];
+#pragma unroll
+            for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                const int c = c0 + lane;
+                rv[c0 / 64] = *reinterpret_cast<const uint4*>(rz + (long long)(c / CPRO) * p.ldr1 + (c % CPRO) * 8);
+            }
+#pragma unroll
+            for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                const int c = c0 + lane;
+                *reinterpret_cast<uint4*>(stage + (c / CPRO) * SROW + (c % CPRO) * 16) = rv[c0 / 64];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         float4 bv[NF];
         if (p.bias) {
 #pragma unroll
@@ -167,7 +189,7 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                 ca = cf[0]; c1 = cf[1]; c2 = cf[2];
             }
             const float* addv = p.add ? p.add + (m / p.add_rpg) * p.add_ld + nb : nullptr;
-            const bf16_t* r1 = p.res1 ? p.res1 + m * p.ldr1 + (int)ncol0 + fq : nullptr;
+            const bf16_t* r1 = (p.res1 && !res1_lds) ? p.res1 + m * p.ldr1 + (int)ncol0 + fq : nullptr;
             const bf16_t* r2 = p.res2 ? p.res2 + m * p.ldr2 + (int)ncol0 + fq : nullptr;
             float* of = p.out_fp32 ? reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + (int)ncol0 + fq : nullptr;
 #pragma unroll
@@ -192,7 +214,10 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                 }
                 const int jo = GEGLU ? (j >> 1) : j;
                 float o[4] = {ca * v[0], ca * v[1], ca * v[2], ca * v[3]};
-                if (r1) {
+                if (CAN_STAGE && res1_lds) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2);
+                    o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
+                } else if (r1) {
                     const uint2 rr = *reinterpret_cast<const uint2*>(r1 + jo * 16);
                     o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
                 }
@@ -202,17 +227,14 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                 }
                 if (of) {
                     *reinterpret_cast<float4*>(of + jo * 16) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
+                } else if (CAN_STAGE) {
                     *reinterpret_cast<uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2) =
                         make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
                 }
             }
         }
-        if (!p.out_fp32) {
+        if (CAN_STAGE && !p.out_fp32) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            constexpr int CPRO = NFO * 2;                  // 16-byte chunks per staged row
-            constexpr int ROWS = MF * 16;
-            static_assert((ROWS * CPRO) % 64 == 0, "staged tile must be a whole number of wave-wide stores");
             bf16_t* outz = reinterpret_cast<bf16_t*>(p.out) + z * p.sO + mw0 * p.ldo + ncol0;
 #pragma unroll
             for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
     constexpr int NFO_ = GEGLU ? NF / 2 : NF;
     constexpr int STAGE_REGION = MF * 16 * (NFO_ * 32 + 16);
     constexpr bool CAN_STAGE = NW * STAGE_REGION <= NS * STAGE_BYTES;   // else: direct MFMA-layout stores
-    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, CAN_STAGE ? lds + wave * STAGE_REGION : nullptr);
+    epilogue<MF, NF, GEGLU, CAN_STAGE>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, lds + (CAN_STAGE ? wave * STAGE_REGION : 0));
 }
 
 // =====================================================================================================================
@@ -525,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
         if (step + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
-    epilogue<MF, NF, GEGLU>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, nullptr);
+    epilogue<MF, NF, GEGLU, false>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, nullptr);
 }
 
 int impl_choice() {
@@ -641,6 +663,7 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
     if ((cfg_choice() == 5 || cfg_choice() == 6) && impl_choice() != 1 && p.N % 256 == 0 && p.K % 64 == 0 && p.K * 2 <= 65536) return launch256<MODE, GEGLU>(p, batch, st, cfg_choice());
     // N tile: 128 unless a 64-wide tile wastes less (e.g. N = 320: 5 x 64 exact vs 3 x 128 = 17 % padding)
     const long long w128 = ((p.N + 127) / 128) * 128, w64 = ((p.N + 63) / 64) * 64;
+    // (64-row tiles for the small-M 8x8 level were measured slower than under-filled 128-row tiles: conv_L3 461 vs 586 TF/s)
     if (w64 < w128) return launch<128, 64, MODE, GEGLU>(p, batch, st);
     return launch<128, 128, MODE, GEGLU>(p, batch, st);
 }
