@@ -14,7 +14,7 @@ from tools.gpu_check import timeit  # noqa: E402
 
 BF = torch.bfloat16
 hip = HipOps()
-tag = f"impl={os.environ.get('V3D_GEMM_IMPL', '2')} cfg={os.environ.get('V3D_GEMM_CFG', '0')}"
+tag = f"impl={os.environ.get('V3D_GEMM_IMPL', '2')} cfg={os.environ.get('V3D_GEMM_CFG', '-')} abl={os.environ.get('V3D_GEMM_ABLATE', '0')}"
 if "--check" in sys.argv:
     import op_cases
     from oracle.ops_emul import EmulOps
@@ -45,6 +45,9 @@ shapes = [
     ("convt_L0_320", dict(N=320, K=320, convt=(2, 18, 4096))),
     ("vae_conv_512sq_128", dict(N=128, K=128, conv=(18, 512, 512))),
 ]
+only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+if only:
+    shapes = [sh for sh in shapes if any(o in sh[0] for o in only[0].split(","))]
 line = []
 for name, d in shapes:
     kw = {}

@@ -41,7 +41,7 @@ agg = collections.OrderedDict()
 for (k, fl), a, b in rec:
     d = agg.setdefault(k, [0, 0.0, 0.0]); d[0] += 1; d[1] += a.elapsed_time(b); d[2] += fl
 tot = sum(v[1] for v in agg.values())
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:400]:
     tf = f"{v[2] / v[1] / 1e9:7.0f} TF/s" if v[2] else ""
     print(f"{v[1]:8.3f} ms {v[1] / tot * 100:5.1f}% n={v[0]:3d} avg={v[1] / v[0] * 1e3:8.1f}us {tf}  {k}")
 print(f"total {tot:.2f} ms over {len(rec)} launches")

@@ -19,6 +19,16 @@ int v3d_check_launch(const char* what) {
     return V3D_OK;
 }
 
+int v3d_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 extern "C" int v3d_abi_version(void) { return V3D_ABI_VERSION; }
 extern "C" const char* v3d_last_error(void) { return g_err; }
 

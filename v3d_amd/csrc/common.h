@@ -76,6 +76,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // host-side error plumbing (defined in capi.hip)
 void v3d_set_error(const char* fmt, ...);
 int v3d_check_launch(const char* what);
+int v3d_num_cus();   // compute units of the current device (cached)
 
 #define V3D_REQUIRE(cond, ...)            \
     do {                                  \

@@ -13,9 +13,21 @@
 // Main loop "v1" (V3D_GEMM_IMPL=1, kept for A/B runs): register-staged double buffer with buffer loads.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
+
+// compile-time loop (bodies that pick between named register arrays must not wait for the late loop unroller: SROA has
+// already given up on the arrays by then and they land in scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 struct GP {
     const bf16_t* A;
@@ -125,9 +137,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // loads, no per-element bounds checks) and the generic path with per-element predicates for ragged M / N edges.
 // (The first version had only the generic path: 1500 VALU + 380 exec-mask branches per wave against 160 MFMAs on the
 // K = 320 GEGLU GEMM, see profiles/r01_gemm_ablation.txt.)
-template <int MF, int NF, bool GEGLU, bool CAN_STAGE>
+// residual #1 rows of one (MF*16) x (NFO*16) wave tile as coalesced 16-byte pieces (the layout the staging buffer uses):
+// piece K of lane l is chunk c = K*64 + l -> row c / CPRO, 16-byte column chunk c % CPRO.  The v3 kernels prefetch these one
+// epilogue chunk ahead and hand them over BY VALUE (a struct / array handed over by reference went through scratch).
+template <int MF, int NF, bool GEGLU>
+struct ResGeom {
+    static constexpr int NFO = GEGLU ? NF / 2 : NF;
+    static constexpr int CPRO = NFO * 2, ROWS = MF * 16, NV = (ROWS * CPRO + 63) / 64;
+};
+template <int K, int MF, int NF, bool GEGLU>
+__device__ __forceinline__ u32x4 load_res_piece(const GP& p, long long mw0, long long nw0, int lane) {
+    using G = ResGeom<MF, NF, GEGLU>;
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if constexpr (K < G::NV) {
+        const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;
+        const int c = K * 64 + lane;
+        if ((G::ROWS * G::CPRO) % 64 == 0 || c < G::ROWS * G::CPRO)
+            r = *reinterpret_cast<const u32x4*>(p.res1 + (mw0 + c / G::CPRO) * p.ldr1 + ncol0 + (c % G::CPRO) * 8);
+    }
+    return r;
+}
+template <int K, int MF, int NF, bool GEGLU>
+__device__ __forceinline__ void res_piece_to_stage(u32x4 r, unsigned char* stage, int srow, int lane) {
+    using G = ResGeom<MF, NF, GEGLU>;
+    if constexpr (K < G::NV) {
+        const int c = K * 64 + lane;
+        if ((G::ROWS * G::CPRO) % 64 == 0 || c < G::ROWS * G::CPRO) *reinterpret_cast<u32x4*>(stage + (c / G::CPRO) * srow + (c % G::CPRO) * 16) = r;
+    }
+}
+
+template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false>
 __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
-                                         unsigned char* stage) {
+                                         unsigned char* stage, u32x4 pre0, u32x4 pre1, u32x4 pre2, bool res_pre) {
     if (p.ablate & 1) {
         float sum = 0.f;
 #pragma unroll
@@ -148,27 +189,34 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                       (!p.add || ((reinterpret_cast<uintptr_t>(p.add) % 16 == 0) && (p.add_ld % 4 == 0))) &&
                       (!p.res1 || reinterpret_cast<uintptr_t>(p.res1) % 8 == 0) && (!p.res2 || reinterpret_cast<uintptr_t>(p.res2) % 8 == 0);
     const int fr = lane & 15, fq = (lane >> 4) * 4;
-    if (fast) {
+    if (FAST_ONLY && (mw0 >= p.M || nw0 >= p.N)) return;   // wave tile completely outside a partial edge tile
+    if (FAST_ONLY || fast) {   // FAST_ONLY: the host has checked the fast-path conditions for every wave tile (v3 kernels)
         const int nb = (int)nw0 + fq;                  // this lane's first packed weight row (tile-relative math in 32 bit)
         constexpr int CPRO = NFO * 2;                  // 16-byte chunks per staged row
         constexpr int ROWS = MF * 16;
-        static_assert((ROWS * CPRO) % 64 == 0, "staged tile must be a whole number of wave-wide stores");
+        constexpr bool WHOLE = (ROWS * CPRO) % 64 == 0;   // else the last wave-wide copy of the staged tile is partial
         // residual #1 comes in through the staging buffer: coalesced 16-byte row loads -> LDS, then each lane picks its 8 bytes in
         // MFMA layout (the direct 8-byte-per-lane residual loads touched 16 rows per instruction: 129 us vs 70 us for the
         // attention out-projection at 64x64, profiles/r01d_op_times_unet_eval.txt)
         const bool res1_lds = CAN_STAGE && p.res1 && !p.out_fp32 && (p.ldr1 % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res1) % 16 == 0);
         if (CAN_STAGE && res1_lds) {
-            const bf16_t* rz = p.res1 + mw0 * p.ldr1 + ncol0;
-            uint4 rv[ROWS * CPRO / 64];
+            if (res_pre) {   // (only offered by callers whose wave-tile chunk has at most 3 pieces per lane)
+                res_piece_to_stage<0, MF, NF, GEGLU>(pre0, stage, SROW, lane);
+                res_piece_to_stage<1, MF, NF, GEGLU>(pre1, stage, SROW, lane);
+                res_piece_to_stage<2, MF, NF, GEGLU>(pre2, stage, SROW, lane);
+            } else {
+                const bf16_t* rz = p.res1 + mw0 * p.ldr1 + ncol0;
+                uint4 rv[(ROWS * CPRO + 63) / 64];
 #pragma unroll
-            for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
-                const int c = c0 + lane;
-                rv[c0 / 64] = *reinterpret_cast<const uint4*>(rz + (long long)(c / CPRO) * p.ldr1 + (c % CPRO) * 8);
-            }
+                for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                    const int c = c0 + lane;
+                    if (WHOLE || c < ROWS * CPRO) rv[c0 / 64] = *reinterpret_cast<const uint4*>(rz + (long long)(c / CPRO) * p.ldr1 + (c % CPRO) * 8);
+                }
 #pragma unroll
-            for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
-                const int c = c0 + lane;
-                *reinterpret_cast<uint4*>(stage + (c / CPRO) * SROW + (c % CPRO) * 16) = rv[c0 / 64];
+                for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                    const int c = c0 + lane;
+                    if (WHOLE || c < ROWS * CPRO) *reinterpret_cast<uint4*>(stage + (c / CPRO) * SROW + (c % CPRO) * 16) = rv[c0 / 64];
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -240,11 +288,12 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
             for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
                 const int c = c0 + lane;
                 const int row = c / CPRO, ch = c % CPRO;
-                *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
+                if (WHOLE || c < ROWS * CPRO) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
             }
         }
         return;
     }
+    if (FAST_ONLY) return;
     // ---------------- generic path (ragged edges) ----------------
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
@@ -301,6 +350,13 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
             }
         }
     }
+}
+
+template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false>
+__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
+                                         unsigned char* stage) {
+    const u32x4 none = {0u, 0u, 0u, 0u};
+    epilogue<MF, NF, GEGLU, CAN_STAGE, FAST_ONLY>(p, acc, mw0, nw0, z, lane, stage, none, none, none, false);
 }
 
 // =====================================================================================================================
@@ -550,11 +606,236 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
     epilogue<MF, NF, GEGLU, false>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, nullptr);
 }
 
+// =====================================================================================================================
+// v3: persistent 8-wave ping-pong pipeline on big tiles (256 x 256, or 192 x 320 for the N = 320 family)
+// =====================================================================================================================
+// Why: a 128 x 128 tile needs (128+128)*2 B of LDS fill per k for 2*128*128 flop = 64 B/clk/CU at the MFMA peak, which is
+// the whole L1/TA fill rate of a CU -- the v2 kernels sit at ~43 % MFMA busy with both resident waves of a SIMD parked on
+// vmcnt at the same time (profiles/r01_gemm_ablation.txt + PMC).  A 256 x 256 tile halves the fill per flop; it leaves one
+// workgroup per CU, so the overlap that v2 got from independent co-resident blocks has to be built into the block:
+//   * 8 waves = 2 groups of 4 (waves w and w+4 share a SIMD).  Every step of 32 k has two slots separated by s_barrier;
+//     in a slot one group runs its 32 MFMAs from registers while the other group issues LDS-DMA for 3 stages ahead and
+//     ds_reads its fragments of the next stage, then they swap (group 1 runs one slot behind group 0).
+//   * persistent: a block walks tiles b, b+G, b+2G ... (XCD-aware order); the (tile, tap, k) stage sequence is flat, so
+//     the ring keeps prefetching across tile boundaries and a group's epilogue overlaps the other group's MFMA slot.
+//   * counted s_waitcnt vmcnt(8): two younger stages (4 DMA ops each per wave) may stay in flight; epilogue stores in
+//     flight only make the count conservative (loads return in order among themselves).
+// retire the finished tile of a v3 wave in chunks of EMF row fragments; residual rows come in one chunk ahead of their use
+// (a per-chunk load -> LDS -> use chain exposed the full load latency 8 times per tile: the [bar] out-projections ran
+// 15-50 % slower than on v2)
+template <int C, int NCH, int EMF, int NF, bool GEGLU>
+__device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH * EMF][NF], long long mw0, long long nw0, int lane, unsigned char* estage,
+                                                 u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre) {
+    static_assert(ResGeom<EMF, NF, GEGLU>::NV <= 3, "v3 epilogue chunk: at most 3 residual pieces per lane");
+    if constexpr (C < NCH) {
+        u32x4 n0 = c0, n1 = c1, n2 = c2;
+        if constexpr (C + 1 < NCH) {
+            if (res_pre) {
+                n0 = load_res_piece<0, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
+                n1 = load_res_piece<1, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
+                n2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
+            }
+        }
+        epilogue<EMF, NF, GEGLU, true, true>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre);
+        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre);
+    }
+}
+
+// slot-level timeline of the v3 loop (V3D_GEMM_ABLATE bit 8, LINEAR only): [group][step 32..63][stamp] s_memtime ticks
+__device__ unsigned long long g_v3_dbg[2 * 32 * 8];
+
+template <int BM, int BN, int WGM, int WGN, int MODE, bool GEGLU, int EMF, bool DBG = false>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
+    constexpr int NS = 4, ROWB = 64, NW = 8;
+    static_assert(WGM * WGN == NW, "8 waves");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MF = WM / 16, NF = WN / 16;
+    static_assert(MF % EMF == 0, "epilogue chunking");
+    constexpr int NPIECE = (BM + BN) / 16;          // 1-KiB pieces (16 rows x 64 B) per stage
+    constexpr int PPW = NPIECE / NW;                // pieces per wave per stage
+    static_assert(PPW * NW == NPIECE && PPW * 2 < 64, "tile / wave-count mismatch");
+    constexpr int APIECES = BM / 16;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int NFO = GEGLU ? NF / 2 : NF;
+    constexpr int EPI_REGION = EMF * 16 * (NFO * 32 + 16);
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE_BYTES + NW * EPI_REGION + (DBG ? 4096 : 0)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lds + NS * STAGE_BYTES + NW * EPI_REGION);
+    const bool dbg_on = DBG && blockIdx.x == 0 && (wave & 3) == 0;
+    auto stamp = [&](int s_, int k) __attribute__((always_inline)) {
+        if (DBG && dbg_on && s_ >= 32 && s_ < 64 && lane == 0) dbg[(grp * 32 + (s_ - 32)) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    const int wm = wave / WGN, wn = wave % WGN;
+    const bf16_t* __restrict__ A = p.A;
+    const bf16_t* __restrict__ W = p.W;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    unsigned char* estage = lds + NS * STAGE_BYTES + wave * EPI_REGION;
+
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    auto tile_origin = [&](int it, long long& m0, long long& n0) __attribute__((always_inline)) {
+        const int id = xcd_remap((int)blockIdx.x + it * G, ntiles);
+        n0 = (long long)(id % p.nt) * BN;
+        m0 = (long long)(id / p.nt) * BM;
+    };
+
+    // ---- loader state (runs up to 3 stages ahead of the consumer, across tile boundaries).  Raw buffer loads straight to
+    //      LDS: per-lane byte offset (row, k-chunk) in a VGPR that only changes per tile / tap, the k position in an SGPR
+    //      soffset -> no vector ALU work per step; padding rows / tails use an out-of-range offset (the load writes zeros).
+    const bufrsrc_t rsA = make_rsrc(A, p.a_bytes);
+    const bufrsrc_t rsW = make_rsrc(W, p.w_bytes);
+    const int prow = lane >> 2;
+    const unsigned kchunk_b = (unsigned)(((lane & 3) ^ swz_row<1>(prow)) * 16);   // every piece starts at a multiple of 16 rows
+    RowInfo<MODE> ri[PPW];
+    unsigned voff[PPW];
+    long long ld_n0 = 0;
+    int ld_it = 0, ld_tap = 0, ld_k0 = 0;
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave + NW * i;
+            if (q < APIECES) {
+                long long s_;
+                const bool ok = ri[i].tap(p, tap, s_);
+                voff[i] = ok ? (unsigned)((s_ + p.a_row0) * p.lda * 2) + kchunk_b : kInvalid;
+            } else {
+                const long long n = ld_n0 + (q - APIECES) * 16 + prow;
+                voff[i] = (n < p.N) ? (unsigned)(((long long)tap * p.N + n) * p.ldw * 2) + kchunk_b : kInvalid;
+            }
+        }
+    };
+    auto set_tile = [&](int it) __attribute__((always_inline)) {
+        long long m0;
+        tile_origin(it, m0, ld_n0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave + NW * i;
+            if (q < APIECES) ri[i].init(p, m0 + q * 16 + prow);
+        }
+        set_tap(0);
+    };
+    set_tile(0);
+    auto issue_piece = [&](int stage, int i) __attribute__((always_inline)) {
+        if (p.ablate & 4) return;
+        const int q = wave + NW * i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)voff[i], ld_k0 * 2, 0, 0);
+    };
+    auto issue_advance = [&]() __attribute__((always_inline)) {
+        ld_k0 += 32;
+        if (ld_k0 >= (int)p.K) {
+            ld_k0 = 0;
+            if (++ld_tap < ntaps<MODE>()) {
+                set_tap(ld_tap);
+            } else {
+                ld_tap = 0;
+                if (++ld_it < my_tiles) set_tile(ld_it);   // past the last tile: harmless re-reads keep the DMA count constant
+                else if (ntaps<MODE>() > 1) set_tap(0);
+            }
+        }
+    };
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) issue_piece(stage, i);
+        issue_advance();
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag_off = (lane & 15) * ROWB + (((lane >> 4) ^ swz_row<1>(lane & 15)) * 16);
+    const int a_base = wm * WM * ROWB;
+    const int b_base = BM * ROWB + wn * WN * ROWB;
+    bf16x8 xf[MF], wf[NF];
+
+    const int nsteps = (int)(p.K / 32) * ntaps<MODE>();
+
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");
+    __builtin_amdgcn_s_barrier();   // B_0: stage 0 landed
+    __builtin_amdgcn_sched_barrier(0);
+    // One barrier B_{s+1} per step ("stage s+1 landed, stage s-... buffers reusable").  Group 0 passes it AFTER its MFMAs of
+    // step s, group 1 BEFORE them: between two barriers group 0 runs {read s, MFMA s} while group 1 runs {MFMA s-1, read s},
+    // so one group's LDS reads / DMA issue always face the other group's MFMAs on the same SIMD.
+    int s = 0;   // flat step counter (ring position)
+    for (int it = 0; it < my_tiles; ++it) {
+        for (int kt = 0; kt < nsteps; ++kt, ++s) {
+            stamp(s, 0);
+            {
+                const unsigned char* sb = lds + (s & 3) * STAGE_BYTES;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + frag_off + i * 16 * ROWB);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_base + frag_off + j * 16 * ROWB);
+            }
+            // refill the ring 3 stages ahead (the buffer of step s-1: its last reader, group 1, finished before B_s) while the
+            // fragment reads are in flight
+            issue((s + 3) & 3);
+            stamp(s, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(s, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 1) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");   // own pieces of stage s+1 landed
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(s, 3);
+            __builtin_amdgcn_s_setprio(1);
+            if (!(p.ablate & 2)) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            stamp(s, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");   // own pieces of stage s+1 landed
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(s, 5);
+        }
+        // ---------------- tile finished for this group: retire it while the other group keeps the MFMA pipe busy
+        long long e_m0, e_n0;
+        tile_origin(it, e_m0, e_n0);
+        {
+            const long long mw0 = e_m0 + wm * WM, nw0 = e_n0 + wn * WN;
+            const bool inside = mw0 < p.M && nw0 < p.N;
+            const bool res_pre = p.res1 && !p.out_fp32 && (p.ldr1 % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res1) % 16 == 0) && inside;
+            u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = r0, r2 = r0;
+            if (res_pre) {
+                r0 = load_res_piece<0, EMF, NF, GEGLU>(p, mw0, nw0, lane);
+                r1 = load_res_piece<1, EMF, NF, GEGLU>(p, mw0, nw0, lane);
+                r2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0, nw0, lane);
+            }
+            v3_retire_chunks<0, MF / EMF, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, r0, r1, r2, res_pre);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DBG && dbg_on && lane < 32)
+        for (int k = 0; k < 8; ++k) g_v3_dbg[(grp * 32 + lane) * 8 + k] = dbg[(grp * 32 + lane) * 8 + k];
+}
+
 int impl_choice() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("V3D_GEMM_IMPL");
-        v = (e && e[0] == '1') ? 1 : 2;
+        v = e ? atoi(e) : 0;   // 0 = heuristic, 1 = v1 only, 2 = v1/v2 only, 3 = v3 wherever it is legal
     }
     return v;
 }
@@ -574,7 +855,7 @@ int launch(const GP& p0, int batch, hipStream_t st) {
     p.mt = (int)((p.M + BM - 1) / BM);
     p.nt = (int)((p.N + BN - 1) / BN);
     dim3 grid((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
-    if (impl_choice() == 1 || p.K % 32 != 0 || p.K * 2 > 65536) {
+    if (impl_choice() == 1 || p.K % 32 != 0 || p.K * 2 > 65536) {   // (impl 0 / 2 / 3 all land here for v2-class shapes)
         // v1 also serves ragged contractions (K % 32 != 0: the 8-channel input conv, odd test shapes)
         hipLaunchKernelGGL((gemm_kernel_v1<BM, BN, MODE, GEGLU>), grid, dim3(256), 0, st, p);
         return v3d_check_launch("v3d_gemm");
@@ -658,8 +939,60 @@ int launch256(const GP& p0, int batch, hipStream_t st, int cfg) {
     return v3d_check_launch("v3d_gemm");
 }
 
+// the v3 kernels only carry the branch-free epilogue: every wave tile (wm x wn) must be fully inside or fully outside the
+// output and all vector-access alignment conditions of the fast path must hold
+bool v3_ok(const GP& p, int wm, int wn) {
+    auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
+    if (p.M % wm || p.N % wn) return false;
+    if (p.out_fp32 ? (p.ldo % 4 != 0 || !al(p.out, 16)) : (p.ldo % 8 != 0 || !al(p.out, 16))) return false;
+    if (p.add && (!al(p.add, 16) || p.add_ld % 4)) return false;
+    if (p.res1 && (!al(p.res1, 8) || p.ldr1 % 4)) return false;
+    if (p.res2 && (!al(p.res2, 8) || p.ldr2 % 4)) return false;
+    if (p.bias && !al(p.bias, 16)) return false;
+    return true;
+}
+
+template <int MODE, bool GEGLU>
+int launch_v3(const GP& p0, hipStream_t st, int variant) {
+    GP p = p0;
+    const int bm = variant == 1 ? 192 : 256, bn = variant == 1 ? 320 : 256;
+    p.mt = (int)((p.M + bm - 1) / bm);
+    p.nt = (int)((p.N + bn - 1) / bn);
+    const int ntiles = p.mt * p.nt;
+    const int grid = ntiles < v3d_num_cus() ? ntiles : v3d_num_cus();
+    if constexpr (MODE == V3D_GEMM_LINEAR && !GEGLU) {
+        if (p.ablate & 8) {
+            hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            return v3d_check_launch("v3d_gemm");
+        }
+    }
+    if constexpr (!GEGLU) {
+        if (variant == 1) {   // the N = 320 family: 192 x 320 tile, wave tile 96 x 80 (147456 rows = 768 tiles = 3 per CU)
+            hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            return v3d_check_launch("v3d_gemm");
+        }
+    }
+    hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+    return v3d_check_launch("v3d_gemm");
+}
+
 template <int MODE, bool GEGLU>
 int dispatch(const GP& p, int batch, hipStream_t st) {
+    // v3 (persistent big tiles) unless forced off (V3D_GEMM_IMPL=1/2), forced on (=3), or the tile count fills the CUs badly
+    if (impl_choice() != 1 && impl_choice() != 2 && cfg_choice() < 0 && batch == 1 && p.K % 32 == 0 && p.K * 2 <= 65536 && p.N >= 256) {
+        const int variant = (!GEGLU && p.N % 320 == 0) ? 1 : 0;
+        const long long bm = variant ? 192 : 256, bn = variant ? 320 : 256;
+        const long long nt3 = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), cus = v3d_num_cus();
+        const double fill3 = (double)nt3 / (double)(((nt3 + cus - 1) / cus) * cus) * ((double)p.N / (double)(((p.N + bn - 1) / bn) * bn));
+        // v2 reference point: 128 x 128 (or x 64) tiles, 2 blocks per CU
+        const long long w128 = ((p.N + 127) / 128) * 128, w64 = ((p.N + 63) / 64) * 64, wv2 = w64 < w128 ? w64 : w128;
+        const long long nt2 = ((p.M + 127) / 128) * (wv2 / (w64 < w128 ? 64 : 128));
+        const double fill2 = (double)nt2 / (double)(((nt2 + 2 * cus - 1) / (2 * cus)) * 2 * cus) * ((double)p.N / (double)wv2);
+        // measured (profiles/r01f_op_times_v3.txt): v3 wins wherever its tiles fill the CUs about as well as v2's do; the
+        // K = 320 GEGLU projection is bound by its epilogue's VALU work, which two independent v2 blocks per CU overlap better
+        const bool want = impl_choice() == 3 || (fill3 >= 0.9 * fill2 && !(GEGLU && p.K < 640));
+        if (want && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 64))) return launch_v3<MODE, GEGLU>(p, st, variant);
+    }
     if ((cfg_choice() == 5 || cfg_choice() == 6) && impl_choice() != 1 && p.N % 256 == 0 && p.K % 64 == 0 && p.K * 2 <= 65536) return launch256<MODE, GEGLU>(p, batch, st, cfg_choice());
     // N tile: 128 unless a 64-wide tile wastes less (e.g. N = 320: 5 x 64 exact vs 3 x 128 = 17 % padding)
     const long long w128 = ((p.N + 127) / 128) * 128, w64 = ((p.N + 63) / 64) * 64;
@@ -669,6 +1002,11 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
 }
 
 }  // namespace
+
+// experiments only (not part of the ABI header): copy the v3 slot timeline out
+extern "C" int v3d_debug_v3_timeline(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v3_dbg), sizeof(g_v3_dbg)) == hipSuccess ? 0 : -1;
+}
 
 extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     V3D_REQUIRE(a != nullptr, "v3d_gemm: null args");
