@@ -104,13 +104,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            // m_new == -inf only if every key so far is masked (cannot happen for sub-tile 0 of tile 0)
-            const float alpha = (m_new == -INFINITY) ? 1.f : exp2f(m_run - m_new);
+            // m_new is finite from sub-tile 0 of tile 0 on (it always holds a valid key); bare v_exp_f32, see the v2 kernel
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float psum = 0.f;
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = (m_new == -INFINITY) ? 0.f : exp2f(sT[r] - m_new);
+                p[r] = __builtin_amdgcn_exp2f(sT[r] - m_new);
                 psum += p[r];
             }
             l_run = l_run * alpha + psum;
@@ -292,29 +292,37 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
         bf16x8 pf[QG][2][2];
         bool any_rescale = false;
         float alpha[QG];
+        if (tail) {   // wave-uniform, last tile only: keys past the end of the sequence must not win the max or add to the sum
+#pragma unroll
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((k0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7)) >= S) sT[g][sub][r] = -INFINITY;
+        }
+        // softmax in the exp2 domain on RAW scores: p = exp2(s * scale2 - m * scale2) is one v_fma + one bare v_exp_f32 per
+        // score (libm's exp2f wraps every v_exp_f32 in a denormal-range compare / select / ldexp: ~6 extra VALU per score, and
+        // the per-score scale multiply and -inf selects were another 3 - the loop was VALU-bound on them)
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             float mx = -INFINITY;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float sc = sT[g][sub][r] * scale2;
-                    if (tail && (k0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7)) >= S) sc = -INFINITY;
-                    sT[g][sub][r] = sc;
-                    mx = fmaxf(mx, sc);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[g][sub][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[g], mx);
-            alpha[g] = (m_new == -INFINITY) ? 1.f : exp2f(m_run[g] - m_new);
+            const float m_new = fmaxf(m_run[g], mx);          // raw-score domain; every tile holds >= 1 valid key, so finite
+            alpha[g] = __builtin_amdgcn_exp2f((m_run[g] - m_new) * scale2);   // first tile: exp2(-inf) = 0 on o = l = 0
             any_rescale |= (alpha[g] != 1.f);
+            const float mb = -m_new * scale2;
             float psum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 float pv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    pv[r] = (m_new == -INFINITY) ? 0.f : exp2f(sT[g][sub][r] - m_new);
+                    pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[g][sub][r], scale2, mb));
                     psum += pv[r];
                 }
 #pragma unroll
