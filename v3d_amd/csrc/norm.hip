@@ -1,5 +1,7 @@
 // GroupNorm (stats / apply), LayerNorm and row softmax for channels-last bf16 activations (gfx950).
 // All of these are HBM-bound: every access is a 16-byte (8 x bf16) per-lane vector, coalesced along channels.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -35,13 +37,18 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
 }
 
 // grid (chunks, n_img); block 256.  Each block reduces rows [chunk*rpb, (chunk+1)*rpb) of one image.
+// NV (vector columns per thread) is a template parameter and the per-channel LDS partials are sized by C (dynamic shared
+// memory): the first version carried the dead second column through every load / fma and declared 32 KiB of LDS, which
+// capped a CU at 5 blocks - 56 us for the 94 MB 64x64 level where the read+write gn_apply takes 36 us.
+template <int NV, int UR>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x1, long long C1,
                                                        const bf16_t* __restrict__ x2, long long C2,
                                                        float* __restrict__ stats, long long S, int groups,
                                                        long long imgs_per_stat, long long rpb) {
-    __shared__ float sh_s[CMAX];
-    __shared__ float sh_q[CMAX];
+    extern __shared__ float gn_sh[];   // [2][C]: per-channel sum, sum of squares
     const long long C = C1 + C2;
+    float* sh_s = gn_sh;
+    float* sh_q = gn_sh + C;
     const GNGeom g = gn_geom(C);
     const int tid = threadIdx.x;
     const long long img = blockIdx.y;
@@ -49,38 +56,34 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     long long r_end = r_begin + rpb;
     if (r_end > S) r_end = S;
 
-    for (int c = tid; c < C; c += 256) {
-        sh_s[c] = 0.f;
-        sh_q[c] = 0.f;
-    }
+    for (int c = tid; c < 2 * C; c += 256) gn_sh[c] = 0.f;
     __syncthreads();
 
     const int trow = tid / g.TPR;
     const int tcol = tid - trow * g.TPR;
-    float s[NVMAX][8], q[NVMAX][8];
+    float s[NV][8], q[NV][8];
 #pragma unroll
-    for (int j = 0; j < NVMAX; ++j)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[j][e] = q[j][e] = 0.f;
 
     if (trow < g.RPP) {
-        // 4 rows per trip: the 4 (x NV) 16-byte loads are issued back to back so several KB per wave are in flight
-        constexpr int UR = 4;
+        // UR rows per trip: the UR (x NV) 16-byte loads are issued back to back so several KB per wave are in flight
         for (long long r = r_begin + trow; r < r_end; r += (long long)UR * g.RPP) {
-            uint4 v[UR][NVMAX];
+            uint4 v[UR][NV];
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const long long rr = r + (long long)u * g.RPP;
 #pragma unroll
-                for (int j = 0; j < NVMAX; ++j) {
+                for (int j = 0; j < NV; ++j) {
                     const int vc = tcol + j * g.TPR;
-                    v[u][j] = (rr < r_end && j < g.NV && vc < g.VC) ? load_vec2(x1, C1, x2, C2, img * S + rr, vc * 8) : make_uint4(0, 0, 0, 0);
+                    v[u][j] = (rr < r_end && vc < g.VC) ? load_vec2(x1, C1, x2, C2, img * S + rr, vc * 8) : make_uint4(0, 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
 #pragma unroll
-                for (int j = 0; j < NVMAX; ++j) {
+                for (int j = 0; j < NV; ++j) {
                     float f[8];
                     unpack8(v[u][j], f);
 #pragma unroll
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
             }
         }
 #pragma unroll
-        for (int j = 0; j < NVMAX; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int v = tcol + j * g.TPR;
-            if (j < g.NV && v < g.VC) {
+            if (v < g.VC) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     atomicAdd(&sh_s[v * 8 + e], s[j][e]);
@@ -192,62 +195,95 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
-// One wave per row, row kept in registers (C <= 64*8*LNV = 2048).
+// A wave normalises RPW rows per pass, every row kept in registers (NVW vectors of 8 channels per lane: C <= 512 * NVW).
+// The loads of all RPW rows are issued before the first reduction, so a wave has RPW x 16 B per lane in flight (the first
+// version handled one row per wave and 4 rows per block: 57 us for the 188 MB of the 64x64 level, gn_apply moves the
+// same bytes in 36 us).
 constexpr int LNV = 4;
+template <int NVW, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ add,
                                                         long long add_rpg, long long add_ld, bf16_t* __restrict__ xsum,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         bf16_t* __restrict__ out, long long M, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= M) return;
     const int VC = C / 8;
-    float f[LNV][8];
-    const float* av = add ? add + (row / add_rpg) * add_ld : nullptr;
-    float sum = 0.f;
+    const float invC = 1.0f / (float)C;
+    float f[RPW][NVW][8];
+    float sum[RPW];
+    uint4 raw[RPW][NVW];
 #pragma unroll
-    for (int j = 0; j < LNV; ++j) {
-        const int v = lane + 64 * j;
-        if (v < VC) {
-            unpack8(*reinterpret_cast<const uint4*>(x + row * C + v * 8), f[j]);
-            if (av) {
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[j][e] += av[v * 8 + e];
+        for (int j = 0; j < NVW; ++j) {
+            const int v = lane + 64 * j;
+            raw[r][j] = (v < VC && row0 + r < M) ? *reinterpret_cast<const uint4*>(x + (row0 + r) * C + v * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long long row = row0 + r;
+        const bool rok = row < M;
+        const float* av = (add && rok) ? add + (row / add_rpg) * add_ld : nullptr;
+        sum[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVW; ++j) {
+            const int v = lane + 64 * j;
+            unpack8(raw[r][j], f[r][j]);
+            if (v < VC && av) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[r][j][e] += av[v * 8 + e];
                 if (xsum) {
-                    uint4 o = make_uint4(pack2bf(f[j][0], f[j][1]), pack2bf(f[j][2], f[j][3]), pack2bf(f[j][4], f[j][5]), pack2bf(f[j][6], f[j][7]));
+                    uint4 o = make_uint4(pack2bf(f[r][j][0], f[r][j][1]), pack2bf(f[r][j][2], f[r][j][3]), pack2bf(f[r][j][4], f[r][j][5]),
+                                         pack2bf(f[r][j][6], f[r][j][7]));
                     *reinterpret_cast<uint4*>(xsum + row * C + v * 8) = o;
-                    unpack8(o, f[j]);  // normalise exactly what was stored
+                    unpack8(o, f[r][j]);  // normalise exactly what was stored
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum += f[j][e];
+            for (int e = 0; e < 8; ++e) sum[r] += f[r][j][e];   // lanes past the row hold zeros
         }
     }
-    sum = wave_sum(sum);
-    const float mean = sum / (float)C;
-    float var = 0.f;
 #pragma unroll
-    for (int j = 0; j < LNV; ++j) {
-        const int v = lane + 64 * j;
-        if (v < VC) {
+    for (int r = 0; r < RPW; ++r) sum[r] = wave_sum(sum[r]);
+    float var[RPW], mean[RPW];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = f[j][e] - mean;
-                var += d * d;
+    for (int r = 0; r < RPW; ++r) {
+        mean[r] = sum[r] * invC;
+        var[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NVW; ++j) {
+            if (lane + 64 * j < VC) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = f[r][j][e] - mean[r];
+                    var[r] += d * d;
+                }
             }
         }
     }
-    var = wave_sum(var) / (float)C;
-    const float rstd = rsqrtf(var + eps);
 #pragma unroll
-    for (int j = 0; j < LNV; ++j) {
+    for (int r = 0; r < RPW; ++r) var[r] = wave_sum(var[r]);
+#pragma unroll
+    for (int j = 0; j < NVW; ++j) {
         const int v = lane + 64 * j;
         if (v < VC) {
-            float y[8];
+            float gm[8], bt[8];
+            *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(gamma + v * 8);
+            *reinterpret_cast<float4*>(gm + 4) = *reinterpret_cast<const float4*>(gamma + v * 8 + 4);
+            *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(beta + v * 8);
+            *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(beta + v * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = (f[j][e] - mean) * rstd * gamma[v * 8 + e] + beta[v * 8 + e];
-            uint4 o = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
-            *reinterpret_cast<uint4*>(out + row * C + v * 8) = o;
+            for (int r = 0; r < RPW; ++r) {
+                if (row0 + r < M) {
+                    const float rstd = rsqrtf(var[r] * invC + eps);
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (f[r][j][e] - mean[r]) * rstd * gm[e] + bt[e];
+                    uint4 o = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
+                    *reinterpret_cast<uint4*>(out + (row0 + r) * C + v * 8) = o;
+                }
+            }
         }
     }
 }
@@ -316,10 +352,24 @@ extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, i
     V3D_REQUIRE(stats != nullptr && imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_stats: bad stats/imgs_per_stat");
     const GNGeom g = gn_geom(C1 + C2);
     long long chunks, rpb;
-    gn_grid(n_img, S, g, chunks, rpb, 2048);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)chunks, (unsigned)n_img), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x1, (long long)C1, (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups,
-                       (long long)imgs_per_stat, rpb);
+    static long long target = -1;
+    if (target < 0) {
+        const char* e = getenv("V3D_GN_BLOCKS");   // tuning knob (tools/gn_bench.py)
+        target = e ? atoll(e) : 0;
+    }
+    // few, long blocks: every block ends in 64 fp32 global atomics and those (not the reads) set the time once there are
+    // more than a few hundred blocks (tools/gn_bench.py: 64x64 level 23 / 26 / 33 / 52 / 94 us at 256 / 512 / 1024 / 2048 /
+    // 4096 blocks); very large inputs (VAE, > 256 MB) want ~3 blocks per CU to keep HBM busy
+    const long long bytes = n_img * S * (C1 + C2) * 2;
+    gn_grid(n_img, S, g, chunks, rpb, target > 0 ? target : (bytes > (256ll << 20) ? 768 : 256));
+    const size_t shmem = (size_t)(C1 + C2) * 2 * sizeof(float);
+    const dim3 grid((unsigned)chunks, (unsigned)n_img);
+    if (g.NV == 1)
+        hipLaunchKernelGGL((gn_stats_kernel<1, 8>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                           (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups, (long long)imgs_per_stat, rpb);
+    else
+        hipLaunchKernelGGL((gn_stats_kernel<2, 4>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                           (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups, (long long)imgs_per_stat, rpb);
     return v3d_check_launch("v3d_groupnorm_stats");
 }
 
@@ -348,10 +398,18 @@ extern "C" int v3d_layernorm(const void* x, const float* add, int64_t add_rpg, i
     V3D_REQUIRE(M > 0, "v3d_layernorm: bad M");
     V3D_REQUIRE(!add || add_rpg > 0, "v3d_layernorm: add_rpg must be > 0");
     V3D_REQUIRE(!xsum_out || add, "v3d_layernorm: xsum_out requires add");
-    const long long blocks = (M + 3) / 4;
+    V3D_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "v3d_layernorm: gamma/beta must be 16-byte aligned");
+    const int nvw = C <= 512 ? 1 : (C <= 1024 ? 2 : 4);
+    const int rpw = nvw == 1 ? 4 : (nvw == 2 ? 2 : 1);
+    const long long blocks = (M + 4 * rpw - 1) / (4 * rpw);
     V3D_REQUIRE(blocks < (1ll << 31), "v3d_layernorm: M too large");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, add,
-                       (long long)add_rpg, (long long)add_ld, (bf16_t*)xsum_out, gamma, beta, (bf16_t*)out, (long long)M, (int)C, eps);
+#define V3D_LN_LAUNCH(NVW_, RPW_)                                                                                                   \
+    hipLaunchKernelGGL((layernorm_kernel<NVW_, RPW_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, add, \
+                       (long long)add_rpg, (long long)add_ld, (bf16_t*)xsum_out, gamma, beta, (bf16_t*)out, (long long)M, (int)C, eps)
+    if (nvw == 1) V3D_LN_LAUNCH(1, 4);
+    else if (nvw == 2) V3D_LN_LAUNCH(2, 2);
+    else V3D_LN_LAUNCH(4, 1);
+#undef V3D_LN_LAUNCH
     return v3d_check_launch("v3d_layernorm");
 }
 
