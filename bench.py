@@ -96,7 +96,11 @@ def measure_gemm_roofline(step):
         e0.record()
         orig(g)
         e1.record()
-        rec.append((e0, e1, 2.0 * g.M * g.N * g.K * taps * g.batch))
+        # algorithmic bytes of the launch: activation rows once + packed weights once + output (+ residuals) once
+        nout = g.N // 2 if g.geglu else g.N
+        by = (g.A.shape[0] * g.K * 2 + taps * g.N * g.K * 2) * g.batch + g.M * nout * g.out.element_size() * g.batch
+        by += sum(g.M * nout * 2 for r in (g.res1, g.res2) if r is not None)
+        rec.append((e0, e1, 2.0 * g.M * g.N * g.K * taps * g.batch, by))
 
     ops.gemm = timed
     try:
@@ -104,13 +108,24 @@ def measure_gemm_roofline(step):
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
-    tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-    flops = sum(f for _, _, f in rec)
+    tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
+    flops = sum(f for _, _, f, _ in rec)
+    alg_bytes = sum(b for _, _, _, b in rec)
     n = len(rec)
     achieved = flops / (tot_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,MODE,GEGLU> (v3d_gemm: conv3x3 / convt3 / linear)",
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes of the same workload (FETCH_SIZE / WRITE_SIZE in
+    # separate runs, calibrated on a copy of known size as MI355X_MICROARCH.md prescribes; tools/pmc_eval.py + pmc_traffic.py)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01h_pmc_traffic.json")))
+        fams = [v for k, v in pmc["families"].items() if k.startswith("gemm_")]
+        traffic = round(sum(v["read_GB_per_eval"] + v["write_GB_per_eval"] for v in fams) * 1e9 / sum(v["launches_per_eval"] for v in fams))
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3<192x320 | 256x256> + gemm_kernel_v2<128x128 ...> (conv3x3 / convt3 / linear / GEGLU)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": None, "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / n, 2),
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC, profiles/r01h_pmc_traffic.txt)",
+            "algorithmic_bytes_per_launch": round(alg_bytes / n), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / n, 2),
             "algorithmic_tflop_per_sample": round(flops / 1e12, 2), "gemm_ms_per_sample": round(tot_ms, 2),
             "measured_on": "one extra instrumented sample after the timed region (HIP events per launch)"}
 

@@ -1,0 +1,60 @@
+"""HBM traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE db, WRITE_SIZE db) of tools/pmc_eval.py.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read stream (MI355X_MICROARCH.md
+section HBM), so the read side is calibrated on the copy kernel of known size in the same run (and the write side too).
+usage: pmc_traffic.py FETCH.db WRITE.db [N_EVAL]"""
+import collections, json, sqlite3, sys
+n_eval = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    cols = [d[1] for d in db.execute("pragma table_info(pmc_events)")]
+    ix = {c: i for i, c in enumerate(cols)}
+    name_c = "name" if "name" in ix else "kernel_name"
+    cn_c = "counter_name" if "counter_name" in ix else "pmc_name"
+    val_c = "value" if "value" in ix else "counter_value"
+    disp_c = "dispatch_id" if "dispatch_id" in ix else None
+    agg = collections.defaultdict(lambda: [0.0, set()])
+    for r in db.execute("select * from pmc_events"):
+        if r[ix[cn_c]] != counter:
+            continue
+        a = agg[r[ix[name_c]]]
+        a[0] += r[ix[val_c]]
+        if disp_c:
+            a[1].add(r[ix[disp_c]])
+    return {k: (v[0], len(v[1])) for k, v in agg.items()}
+
+
+def family(name):
+    for key, fam in (("gemm_kernel_v3", "gemm_v3"), ("gemm_kernel_v2", "gemm_v2"), ("gemm_kernel_v1", "gemm_v1"), ("attn_spatial", "attn_spatial"),
+                     ("attn_temporal", "attn_temporal"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("layernorm", "layernorm"),
+                     ("copy2d", "copy2d(calibration)")):
+        if key in name:
+            return fam
+    return "other"
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+fam = collections.defaultdict(lambda: [0.0, 0.0, 0])
+for k, (v, n) in fetch.items():
+    fam[family(k)][0] += v
+    fam[family(k)][2] += n
+for k, (v, n) in write.items():
+    fam[family(k)][1] += v
+cal = fam.get("copy2d(calibration)")
+known = 4 * 256 * 1024.0   # KiB read (= written) by the 4 calibration copies
+fr = known / cal[0] if cal and cal[0] else 2.0
+fw = known / cal[1] if cal and cal[1] else 1.0
+out = {"calibration": {"fetch_factor": fr, "write_factor": fw, "raw_fetch_KiB": cal[0] if cal else None, "raw_write_KiB": cal[1] if cal else None},
+       "n_eval": n_eval, "families": {}}
+print(f"calibration on 4 x 256 MiB copy: raw FETCH_SIZE {cal[0]:.0f} KiB -> factor {fr:.3f}; raw WRITE_SIZE {cal[1]:.0f} KiB -> factor {fw:.3f}")
+print(f"{'family':22s} {'launches/eval':>13s} {'read GB/eval':>13s} {'write GB/eval':>14s} {'HBM GB/eval':>12s}")
+for f, (rd, wr, n) in sorted(fam.items(), key=lambda kv: -(kv[1][0] * fr + kv[1][1] * fw)):
+    if f.startswith("copy2d"):
+        continue
+    r_gb, w_gb = rd * fr * 1024 / 1e9 / n_eval, wr * fw * 1024 / 1e9 / n_eval
+    out["families"][f] = {"launches_per_eval": n / n_eval, "read_GB_per_eval": r_gb, "write_GB_per_eval": w_gb}
+    print(f"{f:22s} {n / n_eval:13.0f} {r_gb:13.2f} {w_gb:14.2f} {r_gb + w_gb:12.2f}")
+if len(sys.argv) > 4:
+    json.dump(out, open(sys.argv[4], "w"), indent=1)

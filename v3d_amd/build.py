@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libv3d_hip.so")
 ARCH = "gfx950"
+# (-fno-slp-vectorize was tried against the v_pk_*_f32 forms the SLP vectoriser puts into the GEGLU epilogue: no change,
+# 537 vs 545 TF/s on the 64x64 feed-forward projection, 10.55 vs 10.67 frames/s)
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wall", "-Wno-unused-function"]
 

@@ -61,6 +61,19 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// the same function written out for the GEGLU epilogue with bare v_rcp_f32 / v_exp_f32: 5 mul + 7 fma + 1 bfi + 2 transcendental
+__device__ __forceinline__ float gelu_erf_tight(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(z), 0.3275911f, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((z * z) * -1.44269504088896340736f);
+    const float r = __builtin_fmaf(-(p * t), e, 1.0f);     // |erf(z)|
+    const float h = 0.5f * x;
+    return __builtin_fmaf(h, copysignf(r, z), h);          // 0.5 x (1 + erf(z))
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -168,7 +168,8 @@ __device__ __forceinline__ void res_piece_to_stage(u32x4 r, unsigned char* stage
 
 template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false>
 __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
-                                         unsigned char* stage, u32x4 pre0, u32x4 pre1, u32x4 pre2, bool res_pre) {
+                                         unsigned char* stage, u32x4 pre0, u32x4 pre1, u32x4 pre2, bool res_pre,
+                                         const float4 (&bias_pre)[NF], bool has_bias_pre) {
     if (p.ablate & 1) {
         float sum = 0.f;
 #pragma unroll
@@ -221,7 +222,10 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         float4 bv[NF];
-        if (p.bias) {
+        if (has_bias_pre) {   // the caller loaded this wave tile's bias columns once for all of its row chunks
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bv[j] = bias_pre[j];
+        } else if (p.bias) {
 #pragma unroll
             for (int j = 0; j < NF; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + nb + j * 16);
         } else {
@@ -257,7 +261,7 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                         g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w;
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+                    for (int r = 0; r < 4; ++r) v[r] *= (p.ablate & 16) ? g[r] : gelu_erf_tight(g[r]);
                     (void)dummy;
                 }
                 const int jo = GEGLU ? (j >> 1) : j;
@@ -288,7 +292,7 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
             for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
                 const int c = c0 + lane;
                 const int row = c / CPRO, ch = c % CPRO;
-                if (WHOLE || c < ROWS * CPRO) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
+                if ((WHOLE || c < ROWS * CPRO) && !(p.ablate & 32)) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
             }
         }
         return;
@@ -356,7 +360,8 @@ template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false>
 __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
                                          unsigned char* stage) {
     const u32x4 none = {0u, 0u, 0u, 0u};
-    epilogue<MF, NF, GEGLU, CAN_STAGE, FAST_ONLY>(p, acc, mw0, nw0, z, lane, stage, none, none, none, false);
+    float4 nob[NF];
+    epilogue<MF, NF, GEGLU, CAN_STAGE, FAST_ONLY>(p, acc, mw0, nw0, z, lane, stage, none, none, none, false, nob, false);
 }
 
 // =====================================================================================================================
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
 // 15-50 % slower than on v2)
 template <int C, int NCH, int EMF, int NF, bool GEGLU>
 __device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH * EMF][NF], long long mw0, long long nw0, int lane, unsigned char* estage,
-                                                 u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre) {
+                                                 u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre, const float4 (&bv)[NF]) {
     static_assert(ResGeom<EMF, NF, GEGLU>::NV <= 3, "v3 epilogue chunk: at most 3 residual pieces per lane");
     if constexpr (C < NCH) {
         u32x4 n0 = c0, n1 = c1, n2 = c2;
@@ -636,8 +641,8 @@ __device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH *
                 n2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
             }
         }
-        epilogue<EMF, NF, GEGLU, true, true>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre);
-        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre);
+        epilogue<EMF, NF, GEGLU, true, true>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true);
+        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre, bv);
     }
 }
 
@@ -819,7 +824,11 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
                 r1 = load_res_piece<1, EMF, NF, GEGLU>(p, mw0, nw0, lane);
                 r2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0, nw0, lane);
             }
-            v3_retire_chunks<0, MF / EMF, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, r0, r1, r2, res_pre);
+            float4 bv[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                bv[j] = (p.bias && inside) ? *reinterpret_cast<const float4*>(p.bias + (int)nw0 + (lane >> 4) * 4 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v3_retire_chunks<0, MF / EMF, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, r0, r1, r2, res_pre, bv);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -972,7 +981,8 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
             return v3d_check_launch("v3d_gemm");
         }
     }
-    hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+    // epilogue chunk: 2 row fragments for GEGLU (its staged rows are half as wide), 1 otherwise (LDS budget next to the ring)
+    hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, GEGLU ? 2 : 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
     return v3d_check_launch("v3d_gemm");
 }
 
