@@ -61,18 +61,21 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
-// the same function written out for the GEGLU epilogue with bare v_rcp_f32 / v_exp_f32: 5 mul + 7 fma + 1 bfi + 2 transcendental
+// GEGLU epilogue form: erf(z) = 1 - 2^(-z Q(z)) on z = min(|x| / sqrt2, 4) with Q a degree-5 minimax fit of
+// -log2(erfc(z)) / z (tools: scipy erfc, weighted Remez iterations; |erf error| <= 3.3e-7, |gelu error| <= 7.4e-7 in fp32
+// Horner, i.e. the accuracy of the Abramowitz-Stegun form above) - ONE transcendental (v_exp_f32) and 11 plain VALU per
+// value instead of two transcendentals (quarter rate on CDNA4) and 13: the GEGLU epilogue is VALU-bound
+// (tools/gemm_floor.py: the K = 320 projection spends 220 of its 410 us there).
 __device__ __forceinline__ float gelu_erf_tight(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(z), 0.3275911f, 1.0f));
-    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    p = __builtin_fmaf(p, t, 1.421413741f);
-    p = __builtin_fmaf(p, t, -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f((z * z) * -1.44269504088896340736f);
-    const float r = __builtin_fmaf(-(p * t), e, 1.0f);     // |erf(z)|
+    const float z = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
+    float q = __builtin_fmaf(-1.420422594e-04f, z, 3.664275106e-03f);
+    q = __builtin_fmaf(q, z, -3.089617980e-02f);
+    q = __builtin_fmaf(q, z, 1.496994254e-01f);
+    q = __builtin_fmaf(q, z, 9.181654723e-01f);
+    q = __builtin_fmaf(q, z, 1.627925070e+00f);
+    const float r = 1.0f - __builtin_amdgcn_exp2f(-(q * z));   // |erf|
     const float h = 0.5f * x;
-    return __builtin_fmaf(h, copysignf(r, z), h);          // 0.5 x (1 + erf(z))
+    return __builtin_fmaf(h, copysignf(r, x), h);               // 0.5 x (1 + erf(x / sqrt2))
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -221,6 +221,7 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        const bool scale_acc = p.coef != nullptr || p.c_acc != 1.0f;   // wave-uniform
         float4 bv[NF];
         if (has_bias_pre) {   // the caller loaded this wave tile's bias columns once for all of its row chunks
 #pragma unroll
@@ -265,7 +266,11 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                     (void)dummy;
                 }
                 const int jo = GEGLU ? (j >> 1) : j;
-                float o[4] = {ca * v[0], ca * v[1], ca * v[2], ca * v[3]};
+                float o[4] = {v[0], v[1], v[2], v[3]};
+                if (scale_acc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] *= ca;
+                }
                 if (CAN_STAGE && res1_lds) {
                     const uint2 rr = *reinterpret_cast<const uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2);
                     o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
@@ -476,6 +481,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue(s);
 
+    // main-loop waves outrank co-resident blocks that are in their (VALU-dense) epilogue: without it the two do not overlap -
+    // time(K) = time(epilogue only) + time(main loop only) on the GEGLU projections (tools/gemm_floor.py)
+    if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(2);
     for (int t = 0; t < nsteps; ++t) {
         // this wave's pieces of stage t have landed when at most PIECES*(NS-2) newer DMA ops are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (NS - 2)) : "memory");
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (dummy) tail DMAs before the ring is reused / released
     __builtin_amdgcn_s_barrier();                      // every wave has finished reading the last stage
     asm volatile("" ::: "memory");
