@@ -1,0 +1,20 @@
+"""Every v3d_gemm main loop against the oracle emulator on the same cases: the default heuristic only sends launches whose
+tiles fill the CUs to the persistent v3 kernels, so the (smaller) parity shapes are re-run with each implementation forced
+(V3D_GEMM_IMPL is read once per process -> one subprocess per implementation)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["1", "2", "3"])
+def test_gemm_parity_with_forced_impl(impl):
+    env = dict(os.environ, V3D_GEMM_IMPL=impl)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_sweep.py"), "--check", "--only=__none__"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gemm parity failures: 0" in r.stdout, r.stdout + r.stderr

@@ -405,23 +405,47 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(TP p) {
     const long long wave_id = (long long)blockIdx.x * 4 + wave;
     const long long p0 = wave_id * p.G;
 
-    // stage K and V rows: chunk c -> (row = c>>3, kc = c&7), row -> (slot, j)
+    // stage K and V rows: chunk c -> (row = c>>3, kc = c&7), row -> (slot, j).  The (b, s, h) decomposition of a slot's problem
+    // is done once by lane `slot` and fetched with two bpermutes per chunk, and the chunks go in batches of UB: all 2*UB
+    // 16-byte loads of a batch are in flight before the first LDS store (the first version divided 64-bit indices and waited
+    // for its two loads in every one of the ~7 trips: a serial load -> store chain, 194 us against 75 us of HBM time at 64x64)
     const int nchunks = p.G * p.Tk * 8;
-    for (int c = lane; c < nchunks; c += 64) {
-        const int row = c >> 3, kc = c & 7;
-        const int slot = row / p.Tk, j = row - slot * p.Tk;
-        const long long pp = p0 + slot;
-        uint4 uk = make_uint4(0, 0, 0, 0), uv = uk;
-        if (pp < p.P) {
-            const int h = (int)(pp % p.heads);
-            const long long bs = pp / p.heads;
-            const long long s = bs % p.S, b = bs / p.S;
-            const long long off = b * p.kv_sb + (long long)j * p.kv_st + s * p.kv_ss + h * 64 + kc * 8;
-            uk = *reinterpret_cast<const uint4*>(p.k + off);
-            uv = *reinterpret_cast<const uint4*>(p.v + off);
+    long long slot_base = -1;          // element offset of (b, t = 0, s, h) for slot `lane`
+    if (lane < p.G && p0 + lane < p.P) {
+        const long long pp = p0 + lane;
+        const int h = (int)(pp % p.heads);
+        const long long bs = pp / p.heads;
+        const long long s_ = bs % p.S, b_ = bs / p.S;
+        slot_base = b_ * p.kv_sb + s_ * p.kv_ss + h * 64;
+    }
+    constexpr int UB = 4;
+    for (int c0 = 0; c0 < nchunks; c0 += 64 * UB) {
+        uint4 uk[UB], uv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * 64 + lane;
+            const int row = c >> 3, kc = c & 7;
+            const int slot_ = (int)((unsigned)row / (unsigned)p.Tk), j = row - slot_ * p.Tk;
+            const int src_lane = slot_ < 64 ? slot_ : 0;
+            const unsigned lo = (unsigned)__shfl((int)(unsigned)(slot_base & 0xffffffffll), src_lane, 64);
+            const int hi = __shfl((int)(slot_base >> 32), src_lane, 64);
+            const long long base = ((long long)hi << 32) | lo;
+            uk[u] = make_uint4(0, 0, 0, 0);
+            uv[u] = uk[u];
+            if (c < nchunks && base >= 0) {
+                const long long off = base + (long long)j * p.kv_st + kc * 8;
+                uk[u] = *reinterpret_cast<const uint4*>(p.k + off);
+                uv[u] = *reinterpret_cast<const uint4*>(p.v + off);
+            }
         }
-        *reinterpret_cast<uint4*>(sK + row * 64 + kc * 8) = uk;
-        *reinterpret_cast<uint4*>(sV + row * 64 + kc * 8) = uv;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c < nchunks) {
+                *reinterpret_cast<uint4*>(sK + (c >> 3) * 64 + (c & 7) * 8) = uk[u];
+                *reinterpret_cast<uint4*>(sV + (c >> 3) * 64 + (c & 7) * 8) = uv[u];
+            }
+        }
     }
     __syncthreads();
 
@@ -432,53 +456,70 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(TP p) {
     const long long bs = pp / p.heads;
     const long long s = bs % p.S, b = bs / p.S;
 
-    float qv[64];
+    // q stays packed (32 bf16 pairs); scores by v_dot2c_f32_bf16 (2 MACs per instruction, no unpacking), P rounded to bf16
+    // pairs and P.V by dot2 over key pairs with the two V rows interleaved by v_perm_b32: ~1800 VALU per lane instead of
+    // ~4700 (shift/and unpack + fma per element) - the kernel was VALU-bound at 2.5x its HBM time
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    uint32_t qp[32];
     {
-        const bf16_t* qp = p.q + b * p.q_sb + (long long)i * p.q_st + s * p.q_ss + h * 64;
+        const bf16_t* qptr = p.q + b * p.q_sb + (long long)i * p.q_st + s * p.q_ss + h * 64;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const uint4 u = *reinterpret_cast<const uint4*>(qp + c * 8);
-            qv[c * 8 + 0] = bflo(u.x) * p.scale; qv[c * 8 + 1] = bfhi(u.x) * p.scale;
-            qv[c * 8 + 2] = bflo(u.y) * p.scale; qv[c * 8 + 3] = bfhi(u.y) * p.scale;
-            qv[c * 8 + 4] = bflo(u.z) * p.scale; qv[c * 8 + 5] = bfhi(u.z) * p.scale;
-            qv[c * 8 + 6] = bflo(u.w) * p.scale; qv[c * 8 + 7] = bfhi(u.w) * p.scale;
+            const uint4 u = *reinterpret_cast<const uint4*>(qptr + c * 8);
+            qp[c * 4 + 0] = u.x; qp[c * 4 + 1] = u.y; qp[c * 4 + 2] = u.z; qp[c * 4 + 3] = u.w;
         }
     }
     const bf16_t* kk = sK + slot * p.Tk * 64;
     const bf16_t* vv = sV + slot * p.Tk * 64;
+    auto dot2 = [](uint32_t a_, uint32_t b_, float c_) __attribute__((always_inline)) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, a_), __builtin_bit_cast(bf16x2v, b_), c_, false);
+    };
     float sc[TMAX];
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < TMAX; ++j) {
         sc[j] = -INFINITY;
         if (j < p.Tk) {
-            float acc = 0.f;
+            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint4 u = *reinterpret_cast<const uint4*>(kk + j * 64 + c * 8);
-                acc += qv[c * 8 + 0] * bflo(u.x) + qv[c * 8 + 1] * bfhi(u.x) + qv[c * 8 + 2] * bflo(u.y) + qv[c * 8 + 3] * bfhi(u.y) +
-                       qv[c * 8 + 4] * bflo(u.z) + qv[c * 8 + 5] * bfhi(u.z) + qv[c * 8 + 6] * bflo(u.w) + qv[c * 8 + 7] * bfhi(u.w);
+                a0 = dot2(qp[c * 4 + 0], u.x, a0);
+                a1 = dot2(qp[c * 4 + 1], u.y, a1);
+                a0 = dot2(qp[c * 4 + 2], u.z, a0);
+                a1 = dot2(qp[c * 4 + 3], u.w, a1);
             }
-            sc[j] = acc;
-            mx = fmaxf(mx, acc);
+            sc[j] = (a0 + a1) * p.scale;
+            mx = fmaxf(mx, sc[j]);
         }
     }
     float ov[64];
 #pragma unroll
     for (int d = 0; d < 64; ++d) ov[d] = 0.f;
     float l = 0.f;
+    const float mxl = mx * 1.44269504088896340736f;
 #pragma unroll
-    for (int j = 0; j < TMAX; ++j) {
-        if (j < p.Tk) {
-            const float pj = __expf(sc[j] - mx);
-            l += pj;
+    for (int jp = 0; jp < TMAX / 2; ++jp) {
+        if (2 * jp < p.Tk) {
+            const bool two = 2 * jp + 1 < p.Tk;            // wave-uniform
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * jp], 1.44269504088896340736f, -mxl));
+            const float p1 = two ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * jp + 1], 1.44269504088896340736f, -mxl)) : 0.f;
+            const uint32_t pp = pack2bf(p0, p1);
+            l += bflo(pp) + bfhi(pp);                      // normalise by exactly the (rounded) weights that are applied
+            const bf16_t* v0 = vv + (2 * jp) * 64;
+            const bf16_t* v1 = two ? v0 + 64 : v0;         // (weight 0 on the duplicate row)
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const uint4 u = *reinterpret_cast<const uint4*>(vv + j * 64 + c * 8);
-                ov[c * 8 + 0] += pj * bflo(u.x); ov[c * 8 + 1] += pj * bfhi(u.x);
-                ov[c * 8 + 2] += pj * bflo(u.y); ov[c * 8 + 3] += pj * bfhi(u.y);
-                ov[c * 8 + 4] += pj * bflo(u.z); ov[c * 8 + 5] += pj * bfhi(u.z);
-                ov[c * 8 + 6] += pj * bflo(u.w); ov[c * 8 + 7] += pj * bfhi(u.w);
+                const uint4 ua = *reinterpret_cast<const uint4*>(v0 + c * 8);
+                const uint4 ub = *reinterpret_cast<const uint4*>(v1 + c * 8);
+                const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = __builtin_amdgcn_perm(wb[e], wa[e], 0x05040100u);   // (v[j][d], v[j+1][d]),  d = c*8 + 2e
+                    const uint32_t hi = __builtin_amdgcn_perm(wb[e], wa[e], 0x07060302u);   // d + 1
+                    ov[c * 8 + 2 * e] = dot2(pp, lo, ov[c * 8 + 2 * e]);
+                    ov[c * 8 + 2 * e + 1] = dot2(pp, hi, ov[c * 8 + 2 * e + 1]);
+                }
             }
         }
     }
