@@ -50,6 +50,8 @@ struct GP {
     long long S;
     long long sA, sW, sO;
     int mt, nt;  // tile counts
+    int split_n;         // > 1: split-K launch: blockIdx.y = split index = output slab (out = fp32 workspace [split][M][N], plain stores)
+    const float* ws;     // finalize kernel only: the workspace to reduce
     int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads
 };
 
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
     const int tile_m = bid / p.nt;
     const long long m0 = (long long)tile_m * BM;
     const long long n0 = (long long)tile_n * BN;
-    const long long z = blockIdx.y;
+    const long long z = blockIdx.y;                       // batch index, or split index of a split-K launch (sA = sW = 0 then)
     const bf16_t* __restrict__ A = p.A + z * p.sA;
     const bf16_t* __restrict__ W = p.W + z * p.sW;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
@@ -445,9 +447,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
         }
     };
     const int ksteps = (int)(p.K / BK2);                 // host guarantees K % BK2 == 0 for this kernel
-    const int nsteps = ksteps * ntaps<MODE>();
-    int ld_tap = 0, ld_k0 = 0;
-    set_tap(0);
+    // split-K: this block contracts the flat (tap, k) step range [s0, s1) only
+    const int total_steps = ksteps * ntaps<MODE>();
+    const int s0 = p.split_n > 1 ? (int)((long long)total_steps * blockIdx.y / p.split_n) : 0;
+    const int s1 = p.split_n > 1 ? (int)((long long)total_steps * (blockIdx.y + 1) / p.split_n) : total_steps;
+    const int nsteps = s1 - s0;
+    int ld_tap = s0 / ksteps, ld_k0 = (s0 - ld_tap * ksteps) * BK2;
+    set_tap(ld_tap);
     // steps issued past the end of the contraction (ring tail) re-read valid rows of the last tap: harmless dummies that
     // keep the per-wave DMA count per stage constant for the counted vmcnt waits
     auto issue = [&](int stage) {
@@ -849,6 +855,66 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
         for (int k = 0; k < 8; ++k) g_v3_dbg[(grp * 32 + lane) * 8 + k] = dbg[(grp * 32 + lane) * 8 + k];
 }
 
+// ---- split-K finalize: out = epilogue(sum over splits of ws) element-wise (4 consecutive channels per thread) ---------------------
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(GP p) {
+    const long long n4 = p.N / 4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.M * n4) return;
+    const long long m = idx / n4;
+    const int n = (int)(idx - m * n4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < p.split_n; ++sp) {
+        const float4 w = *reinterpret_cast<const float4*>(p.ws + ((long long)sp * p.M + m) * p.N + n);
+        a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w;
+    }
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (p.add) {
+        const float4 b = *reinterpret_cast<const float4*>(p.add + (m / p.add_rpg) * p.add_ld + n);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
+    if (p.coef) {
+        const float* cf = p.coef + (m / p.coef_rpg) * 3;
+        ca = cf[0]; c1 = cf[1]; c2 = cf[2];
+    }
+    float o[4] = {ca * a.x, ca * a.y, ca * a.z, ca * a.w};
+    if (p.res1) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.res1 + m * p.ldr1 + n);
+        o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
+    }
+    if (p.res2) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.res2 + m * p.ldr2 + n);
+        o[0] += c2 * bflo(rr.x); o[1] += c2 * bfhi(rr.x); o[2] += c2 * bflo(rr.y); o[3] += c2 * bfhi(rr.y);
+    }
+    if (p.out_fp32)
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * p.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + m * p.ldo + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+}
+
+// library-owned fp32 workspace of the split-K path (one per process, single-stream use like every other entry point; grows on
+// demand).  Partials are written with plain stores, one slab per split: fp32 atomics into one slab were tried first and
+// made the launch 1.4-2.5x slower than not splitting at all (8.8 M atomics per 8x8 conv).
+float* splitk_workspace(size_t floats, hipStream_t st) {
+    static float* ws = nullptr;
+    static size_t cap = 0;
+    if (floats > cap) {
+        if (ws) {
+            hipStreamSynchronize(st);
+            hipFree(ws);
+        }
+        ws = nullptr;
+        cap = 0;
+        const size_t want = floats + floats / 2;
+        if (hipMalloc(reinterpret_cast<void**>(&ws), want * sizeof(float)) != hipSuccess) return nullptr;
+        cap = want;
+    }
+    return ws;
+}
+
 int impl_choice() {
     static int v = -1;
     if (v < 0) {
@@ -867,12 +933,53 @@ int cfg_choice() {
     return v;
 }
 
+int splitk_choice() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("V3D_GEMM_SPLITK");   // 0 = never, N = force N-way where legal, unset = heuristic
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 template <int BM, int BN, int MODE, bool GEGLU>
 int launch(const GP& p0, int batch, hipStream_t st) {
     GP p = p0;
     p.mt = (int)((p.M + BM - 1) / BM);
     p.nt = (int)((p.N + BN - 1) / BN);
     dim3 grid((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
+    // split-K: the 8x8 level has 180 tiles of 128 x 128 for 256 CUs and contractions of 160-720 steps, so a launch lasts as long as
+    // ONE tile (conv 8x8 1280->1280: 153 us, 444 TF/s).  Splitting the flat (tap, k) range 2-4 ways fills the CUs; the partial sums
+    // meet in an fp32 workspace (atomics) and a small finalize kernel applies the epilogue.
+    if constexpr (!GEGLU && BM == 128) {
+        const long long tiles = (long long)p.mt * p.nt, cus = v3d_num_cus();
+        const long long steps = (long long)ntaps<MODE>() * (p.K / 32);
+        int want = splitk_choice();
+        if (want < 0) want = (tiles * 4 <= cus * 3 && steps >= 96) ? (int)((3 * cus + tiles - 1) / tiles) : 1;   // 8x8 conv: 546 / 693 / 617 / 699 TF/s at 1 / 2 / 3 / 4
+        if (want > 4) want = 4;
+        if (want > steps / 32) want = (int)(steps / 32);
+        if (want > 1 && batch == 1 && impl_choice() != 1 && p.K % 64 == 0 && p.K * 2 <= 65536 && p.N % 4 == 0 && p.ldo % 4 == 0 &&
+            (!p.res1 || (p.ldr1 % 4 == 0 && reinterpret_cast<uintptr_t>(p.res1) % 8 == 0)) &&
+            (!p.res2 || (p.ldr2 % 4 == 0 && reinterpret_cast<uintptr_t>(p.res2) % 8 == 0)) &&
+            (!p.add || (p.add_ld % 4 == 0 && reinterpret_cast<uintptr_t>(p.add) % 16 == 0)) &&
+            reinterpret_cast<uintptr_t>(p.out) % 16 == 0) {
+            float* ws = splitk_workspace((size_t)want * (size_t)p.M * (size_t)p.N, st);
+            if (ws) {
+                GP q = p;                 // the split launch: plain fp32 partial sums, slab `split`
+                q.split_n = want;
+                q.out = ws; q.out_fp32 = 1; q.ldo = p.N; q.sO = p.M * p.N; q.sA = 0; q.sW = 0;
+                q.bias = nullptr; q.add = nullptr; q.res1 = nullptr; q.res2 = nullptr; q.coef = nullptr;
+                q.c_acc = 1.f; q.c_res1 = 0.f; q.c_res2 = 0.f;
+                dim3 g2((unsigned)(p.mt * p.nt), (unsigned)want, 1);
+                hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), g2, dim3(256), 0, st, q);
+                p.split_n = want;
+                p.ws = ws;
+                const long long n4 = p.M * (p.N / 4);
+                hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p);
+                return v3d_check_launch("v3d_gemm(split-K)");
+            }
+        }
+    }
     if (impl_choice() == 1 || p.K % 32 != 0 || p.K * 2 > 65536) {   // (impl 0 / 2 / 3 all land here for v2-class shapes)
         // v1 also serves ragged contractions (K % 32 != 0: the 8-channel input conv, odd test shapes)
         hipLaunchKernelGGL((gemm_kernel_v1<BM, BN, MODE, GEGLU>), grid, dim3(256), 0, st, p);
@@ -1062,6 +1169,8 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     p.T = a->T; p.tmin = a->tmin; p.tmax = a->tmax; p.S = a->S;
     p.sA = a->sA; p.sW = a->sW; p.sO = a->sO;
     p.mt = p.nt = 0;
+    p.split_n = 1;
+    p.ws = nullptr;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("V3D_GEMM_ABLATE"); ab = e ? atoi(e) : 0; } p.ablate = ab; }
     hipStream_t st = (hipStream_t)stream;
     switch (a->mode) {
