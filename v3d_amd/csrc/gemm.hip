@@ -168,7 +168,7 @@ __device__ __forceinline__ void res_piece_to_stage(u32x4 r, unsigned char* stage
     }
 }
 
-template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false>
+template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false, int SPAD = 16>
 __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
                                          unsigned char* stage, u32x4 pre0, u32x4 pre1, u32x4 pre2, bool res_pre,
                                          const float4 (&bias_pre)[NF], bool has_bias_pre) {
@@ -183,7 +183,7 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
     }
     const long long Nout = GEGLU ? p.N / 2 : p.N;
     constexpr int NFO = GEGLU ? NF / 2 : NF;          // output fragments per wave-tile row
-    constexpr int SROW = NFO * 32 + 16;               // staging row stride in bytes (16 B pad)
+    constexpr int SROW = NFO * 32 + SPAD;             // staging row stride in bytes (16 B pad unless LDS is too tight)
     const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;   // first output column of this wave tile
     const bool staged = CAN_STAGE && !p.out_fp32 && (p.ldo % 8 == 0) && (ncol0 % 8 == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.out) + (size_t)z * p.sO * 2) % 16 == 0);
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
 // retire the finished tile of a v3 wave in chunks of EMF row fragments; residual rows come in one chunk ahead of their use
 // (a per-chunk load -> LDS -> use chain exposed the full load latency 8 times per tile: the [bar] out-projections ran
 // 15-50 % slower than on v2)
-template <int C, int NCH, int EMF, int NF, bool GEGLU>
+template <int C, int NCH, int EMF, int NF, bool GEGLU, int SPAD>
 __device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH * EMF][NF], long long mw0, long long nw0, int lane, unsigned char* estage,
                                                  u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre, const float4 (&bv)[NF]) {
     static_assert(ResGeom<EMF, NF, GEGLU>::NV <= 3, "v3 epilogue chunk: at most 3 residual pieces per lane");
@@ -656,17 +656,19 @@ __device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH *
                 n2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
             }
         }
-        epilogue<EMF, NF, GEGLU, true, true>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true);
-        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre, bv);
+        epilogue<EMF, NF, GEGLU, true, true, SPAD>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true);
+        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU, SPAD>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre, bv);
     }
 }
 
 // slot-level timeline of the v3 loop (V3D_GEMM_ABLATE bit 8, LINEAR only): [group][step 32..63][stamp] s_memtime ticks
 __device__ unsigned long long g_v3_dbg[2 * 32 * 8];
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool GEGLU, int EMF, bool DBG = false>
-__global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
-    constexpr int NS = 4, ROWB = 64, NW = 8;
+template <int BM, int BN, int WGM, int WGN, int MODE, bool GEGLU, int EMF, bool DBG = false, int NS = 4, int SPAD = 16>
+__global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int ntiles) {   // (HIP: 2nd arg = min waves per SIMD)
+    // NS = 4: one block per CU (128 KiB ring).  NS = 3 with a 256 x 128 tile: 72 KiB ring + 8 KiB staging = 80 KiB -> TWO blocks per
+    // CU (128 VGPRs per wave), so one block's VALU-bound epilogue (GEGLU) overlaps the other block's main loop.
+    constexpr int ROWB = 64, NW = 8;
     static_assert(WGM * WGN == NW, "8 waves");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MF = WM / 16, NF = WN / 16;
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
     constexpr int APIECES = BM / 16;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int NFO = GEGLU ? NF / 2 : NF;
-    constexpr int EPI_REGION = EMF * 16 * (NFO * 32 + 16);
+    constexpr int EPI_REGION = EMF * 16 * (NFO * 32 + SPAD);
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE_BYTES + NW * EPI_REGION + (DBG ? 4096 : 0)];
 
     const int tid = threadIdx.x;
@@ -775,21 +777,21 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
 
     const int nsteps = (int)(p.K / 32) * ntaps<MODE>();
 
-    issue(0);
-    issue(1);
-    issue(2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue(st);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");
     __builtin_amdgcn_s_barrier();   // B_0: stage 0 landed
     __builtin_amdgcn_sched_barrier(0);
     // One barrier B_{s+1} per step ("stage s+1 landed, stage s-... buffers reusable").  Group 0 passes it AFTER its MFMAs of
     // step s, group 1 BEFORE them: between two barriers group 0 runs {read s, MFMA s} while group 1 runs {MFMA s-1, read s},
     // so one group's LDS reads / DMA issue always face the other group's MFMAs on the same SIMD.
-    int s = 0;   // flat step counter (ring position)
+    int s = 0;        // flat step counter
+    int rd = 0;       // ring slot of step s; the refill target (step s + NS - 1) is the slot before it
     for (int it = 0; it < my_tiles; ++it) {
         for (int kt = 0; kt < nsteps; ++kt, ++s) {
             stamp(s, 0);
             {
-                const unsigned char* sb = lds + (s & 3) * STAGE_BYTES;
+                const unsigned char* sb = lds + rd * STAGE_BYTES;
 #pragma unroll
                 for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + frag_off + i * 16 * ROWB);
 #pragma unroll
@@ -797,13 +799,14 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
             }
             // refill the ring 3 stages ahead (the buffer of step s-1: its last reader, group 1, finished before B_s) while the
             // fragment reads are in flight
-            issue((s + 3) & 3);
+            issue(rd == 0 ? NS - 1 : rd - 1);
+            rd = (rd + 1 == NS) ? 0 : rd + 1;
             stamp(s, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stamp(s, 2);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 1) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");   // own pieces of stage s+1 landed
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");   // own pieces of stage s+1 landed
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
             stamp(s, 4);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");   // own pieces of stage s+1 landed
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");   // own pieces of stage s+1 landed
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v3(GP p, int ntiles) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
                 bv[j] = (p.bias && inside) ? *reinterpret_cast<const float4*>(p.bias + (int)nw0 + (lane >> 4) * 4 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v3_retire_chunks<0, MF / EMF, EMF, NF, GEGLU>(p, acc, mw0, nw0, lane, estage, r0, r1, r2, res_pre, bv);
+            v3_retire_chunks<0, MF / EMF, EMF, NF, GEGLU, SPAD>(p, acc, mw0, nw0, lane, estage, r0, r1, r2, res_pre, bv);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -1077,10 +1080,19 @@ bool v3_ok(const GP& p, int wm, int wn) {
     return true;
 }
 
+int v3s_choice() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("V3D_GEMM_V3S");   // 1 enables the two-blocks-per-CU GEGLU variant (A/B runs; not faster: 402 vs 396 us)
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <int MODE, bool GEGLU>
 int launch_v3(const GP& p0, hipStream_t st, int variant) {
     GP p = p0;
-    const int bm = variant == 1 ? 192 : 256, bn = variant == 1 ? 320 : 256;
+    const int bm = variant == 1 ? 192 : 256, bn = variant == 1 ? 320 : (variant == 2 ? 128 : 256);
     p.mt = (int)((p.M + bm - 1) / bm);
     p.nt = (int)((p.N + bn - 1) / bn);
     const int ntiles = p.mt * p.nt;
@@ -1091,9 +1103,26 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
             return v3d_check_launch("v3d_gemm");
         }
     }
+    if constexpr (GEGLU && MODE == V3D_GEMM_LINEAR) {
+        if (variant == 2) {   // epilogue-bound GEGLU projections (K = 320): 256 x 128 tile, two blocks per CU
+            const int g2 = ntiles < 2 * v3d_num_cus() ? ntiles : 2 * v3d_num_cus();
+            hipLaunchKernelGGL((gemm_kernel_v3<256, 128, 4, 2, MODE, GEGLU, 1, false, 3, 0>), dim3(g2), dim3(512), 0, st, p, ntiles);
+            return v3d_check_launch("v3d_gemm");
+        }
+    }
     if constexpr (!GEGLU) {
         if (variant == 1) {   // the N = 320 family: 192 x 320 tile, wave tile 96 x 80 (147456 rows = 768 tiles = 3 per CU)
             hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            return v3d_check_launch("v3d_gemm");
+        }
+    }
+    if constexpr (GEGLU) {
+        // GEGLU halves the output width: with waves laid out 4 (M) x 2 (N) a wave owns 128 weight rows = 64 output channels = whole
+        // 128-byte lines of every output row (the 2 x 4 layout wrote 64-byte half lines from two different waves)
+        // measured (tools/gemm_floor.py, M = 147456, N = 2560): K = 320: 396 us vs 416 us (2 x 4) vs 402 us (two 256 x 128 blocks
+        // per CU) vs 421 us (v2); at K >= 640 the 2 x 4 layout with 32-row chunks is ahead again (tools/gemm_sweep.py)
+        if (p.K < 640 && !(p.ablate & 128)) {
+            hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 4, 2, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
     }
@@ -1114,10 +1143,10 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
         const long long w128 = ((p.N + 127) / 128) * 128, w64 = ((p.N + 63) / 64) * 64, wv2 = w64 < w128 ? w64 : w128;
         const long long nt2 = ((p.M + 127) / 128) * (wv2 / (w64 < w128 ? 64 : 128));
         const double fill2 = (double)nt2 / (double)(((nt2 + 2 * cus - 1) / (2 * cus)) * 2 * cus) * ((double)p.N / (double)wv2);
-        // measured (profiles/r01f_op_times_v3.txt): v3 wins wherever its tiles fill the CUs about as well as v2's do; the
-        // K = 320 GEGLU projection is bound by its epilogue's VALU work, which two independent v2 blocks per CU overlap better
-        const bool want = impl_choice() == 3 || (fill3 >= 0.9 * fill2 && !(GEGLU && p.K < 640));
-        if (want && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 64))) return launch_v3<MODE, GEGLU>(p, st, variant);
+        // measured (profiles/r01f_op_times_v3.txt): v3 wins wherever its tiles fill the CUs about as well as v2's do
+        if (GEGLU && p.K < 640 && v3s_choice() && v3_ok(p, 64, 64) && p.M >= 256ll * 2 * cus / 4) return launch_v3<MODE, GEGLU>(p, st, 2);
+        const bool want = impl_choice() == 3 || fill3 >= 0.9 * fill2;
+        if (want && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) return launch_v3<MODE, GEGLU>(p, st, variant);
     }
     if ((cfg_choice() == 5 || cfg_choice() == 6) && impl_choice() != 1 && p.N % 256 == 0 && p.K % 64 == 0 && p.K * 2 <= 65536) return launch256<MODE, GEGLU>(p, batch, st, cfg_choice());
     // N tile: 128 unless a 64-wide tile wastes less (e.g. N = 320: 5 x 64 exact vs 3 x 128 = 17 % padding)
