@@ -1144,7 +1144,8 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
         const long long nt2 = ((p.M + 127) / 128) * (wv2 / (w64 < w128 ? 64 : 128));
         const double fill2 = (double)nt2 / (double)(((nt2 + 2 * cus - 1) / (2 * cus)) * 2 * cus) * ((double)p.N / (double)wv2);
         // measured (profiles/r01f_op_times_v3.txt): v3 wins wherever its tiles fill the CUs about as well as v2's do
-        if (GEGLU && p.K < 640 && v3s_choice() && v3_ok(p, 64, 64) && p.M >= 256ll * 2 * cus / 4) return launch_v3<MODE, GEGLU>(p, st, 2);
+        if (GEGLU && p.K < 640 && v3s_choice() && v3_ok(p, 64, 64) && ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * cus)
+            return launch_v3<MODE, GEGLU>(p, st, 2);
         const bool want = impl_choice() == 3 || fill3 >= 0.9 * fill2;
         if (want && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) return launch_v3<MODE, GEGLU>(p, st, variant);
     }
