@@ -11,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl", ["1", "2", "3"])
-def test_gemm_parity_with_forced_impl(impl):
-    env = dict(os.environ, V3D_GEMM_IMPL=impl)
+@pytest.mark.parametrize("impl,extra", [("1", {}), ("2", {}), ("3", {}), ("2", {"V3D_GEMM_SPLITK": "3"}), ("3", {"V3D_GEMM_V3S": "0"})])
+def test_gemm_parity_with_forced_impl(impl, extra):
+    env = dict(os.environ, V3D_GEMM_IMPL=impl, **extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_sweep.py"), "--check", "--only=__none__"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr

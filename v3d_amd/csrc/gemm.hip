@@ -1146,7 +1146,12 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
         // measured (profiles/r01f_op_times_v3.txt): v3 wins wherever its tiles fill the CUs about as well as v2's do
         if (GEGLU && p.K < 640 && v3s_choice() && v3_ok(p, 64, 64) && ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * cus)
             return launch_v3<MODE, GEGLU>(p, st, 2);
-        const bool want = impl_choice() == 3 || fill3 >= 0.9 * fill2;
+        static double fill_k = -1.0;
+        if (fill_k < 0) {
+            const char* e = getenv("V3D_GEMM_FILL");   // tuning knob
+            fill_k = e ? atof(e) : 0.9;
+        }
+        const bool want = impl_choice() == 3 || fill3 >= fill_k * fill2;
         if (want && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) return launch_v3<MODE, GEGLU>(p, st, variant);
     }
     if ((cfg_choice() == 5 || cfg_choice() == 6) && impl_choice() != 1 && p.N % 256 == 0 && p.K % 64 == 0 && p.K * 2 <= 65536) return launch256<MODE, GEGLU>(p, batch, st, cfg_choice());
