@@ -802,16 +802,20 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
             issue(rd == 0 ? NS - 1 : rd - 1);
             rd = (rd + 1 == NS) ? 0 : rd + 1;
             stamp(s, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // group 1 must have its fragments in registers before it passes the barrier (the slot is refilled after it);
+            // group 0 goes straight into its MFMAs and lets the compiler's counted lgkmcnt waits release them fragment by fragment
+            if (grp == 1 || (p.ablate & 512)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
             stamp(s, 2);
-            __builtin_amdgcn_sched_barrier(0);
             if (grp == 1) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");   // own pieces of stage s+1 landed
                 __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             stamp(s, 3);
-            __builtin_amdgcn_s_setprio(1);
+            if (!(p.ablate & 256)) __builtin_amdgcn_s_setprio(1);
             if (!(p.ablate & 2)) {
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
                     for (int j = 0; j < NF; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (!(p.ablate & 256)) __builtin_amdgcn_s_setprio(0);
             stamp(s, 4);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) {
