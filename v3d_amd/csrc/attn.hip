@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
 //   * QG query groups of 32 per wave share every K / V^T fragment read (QG = 2 for long sequences);
 //   * one softmax update per 64-key tile (not per 32), O rescale skipped when no running max moved in the wave.
 // ------------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(256))) unsigned int g_attn_zero[64] = {0};
 
 template <int QG>
 __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* __restrict__ q, long long ldq,
@@ -200,37 +199,36 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
             qf[g][st] = __builtin_bit_cast(bf16x8, buf_load16(rsQ, qrow < S ? (unsigned)((qrow * ldq + hi * 8 + st * 16) * 2) : kInvalid));
     }
 
-    // ---- LDS-DMA sources: piece = 8 rows x 128 B; lane l -> row (l >> 3), chunk position (l & 7), logical chunk pos ^ swz
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero);
+    // ---- LDS-DMA sources: piece = 8 rows x 128 B; lane l -> row (l >> 3), chunk position (l & 7), logical chunk pos ^ swz.
+    //      Raw buffer loads to LDS with the whole byte offset in a VGPR that advances by a constant per tile (one v_add per piece):
+    //      keys past the end of the sequence fall outside the K descriptor and arrive as zeros; the V^T tail columns of the last
+    //      tile read the start of the next d-row (finite values, or zeros past the slab) and meet P = 0 there.  (The first version
+    //      recomputed 64-bit pointers with bounds selects per tile: ~60 VALU / SALU instructions, 15 % of the loop.)
     const int prow = lane >> 3;
-    const bf16_t* kbase = k + n * S * ldk + h * 64;
-    const bf16_t* vbase = vT + (n * C + h * 64) * S;
-    int krow[2], vrow[2], kch[2], vch[2];
+    const bufrsrc_t rsK = make_rsrc(k + n * S * ldk + h * 64, (unsigned)(((S - 1) * ldk + 64) * 2));
+    const bufrsrc_t rsV = make_rsrc(vT + (n * C + h * 64) * S, (unsigned)(64 * S * 2));
+    unsigned koffs[2], voffs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        krow[i] = (wave * 2 + i) * 8 + prow;          // key row within the tile / d row of V^T
-        vrow[i] = krow[i];
-        kch[i] = (lane & 7) ^ ((krow[i] >> 1) & 7);
-        vch[i] = kch[i];
+        const int row = (wave * 2 + i) * 8 + prow;          // key row within the tile / d row of V^T
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        koffs[i] = (unsigned)((row * ldk + ch * 8) * 2);
+        voffs[i] = (unsigned)(((long long)row * S + ch * 8) * 2);
     }
+    const unsigned kstep = (unsigned)(64 * ldk * 2);
     const int ntiles = (int)((S + 63) / 64);
-    int ld_tile = 0;
     auto issue = [&](int stage) {
         unsigned char* sb = lds + stage * TILE_BYTES;
-        const long long k0 = (long long)ld_tile * 64;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bool ok = ld_tile < ntiles && (k0 + krow[i]) < S;
-            const bf16_t* g = ok ? kbase + (k0 + krow[i]) * ldk + kch[i] * 8 : zero;
-            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sb + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(sb + (wave * 2 + i) * 1024), 16, (int)koffs[i], 0, 0, 0);
+            koffs[i] += kstep;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bool ok = ld_tile < ntiles && (k0 + vch[i] * 8) < S;
-            const bf16_t* g = ok ? vbase + (long long)vrow[i] * S + k0 + vch[i] * 8 : zero;
-            __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(sb + 8192 + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(sb + 8192 + (wave * 2 + i) * 1024), 16, (int)voffs[i], 0, 0, 0);
+            voffs[i] += 128u;
         }
-        ++ld_tile;
     };
 
     // fragment read offsets.  K: MFMA row i = qi holds key pi(i); logical chunk = 2*st + hi.
@@ -542,7 +540,8 @@ extern "C" int v3d_attn_spatial(const void* q, int64_t ldq, const void* k, int64
     V3D_REQUIRE(S % 8 == 0, "v3d_attn_spatial: S must be a multiple of 8 (got %lld)", (long long)S);
     V3D_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "v3d_attn_spatial: ldq/ldk must be multiples of 8, ldo of 4");
     V3D_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vT) & 15) == 0 && ((uintptr_t)out & 7) == 0, "v3d_attn_spatial: misaligned pointer");
-    V3D_REQUIRE((unsigned long long)S * (ldq > ldk ? ldq : ldk) * 2ull <= kMaxBufBytes, "v3d_attn_spatial: per-image q/k slab exceeds 4 GiB");
+    V3D_REQUIRE((unsigned long long)(S + 192) * (ldq > ldk ? ldq : ldk) * 2ull <= kMaxBufBytes && (unsigned long long)(64 * S + 256) * 2ull <= kMaxBufBytes,
+                "v3d_attn_spatial: per-image q / k / v slab exceeds 4 GiB");
     static int impl = -1;
     if (impl < 0) {
         const char* e = getenv("V3D_ATTN_IMPL");
