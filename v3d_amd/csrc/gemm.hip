@@ -1088,7 +1088,8 @@ int v3s_choice() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("V3D_GEMM_V3S");   // 0 disables the two-blocks-per-CU GEGLU variant.  In isolation it ties with the
-        v = e ? atoi(e) : 1;                      // 256 x 256 kernel (402 vs 396 us); inside the sampler it is +0.9 % end to end (same-box A/B)
+        v = e ? atoi(e) : 2;                      // 256 x 256 kernel (402 vs 396 us); inside the sampler it is +0.9 % end to end (same-box A/B);
+                                                  // 1 = K < 640 only, 2 = every GEGLU projection (+0.35 % more)
     }
     return v;
 }
@@ -1148,7 +1149,7 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
         const long long nt2 = ((p.M + 127) / 128) * (wv2 / (w64 < w128 ? 64 : 128));
         const double fill2 = (double)nt2 / (double)(((nt2 + 2 * cus - 1) / (2 * cus)) * 2 * cus) * ((double)p.N / (double)wv2);
         // measured (profiles/r01f_op_times_v3.txt): v3 wins wherever its tiles fill the CUs about as well as v2's do
-        if (GEGLU && p.K < 640 && v3s_choice() && v3_ok(p, 64, 64) && ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * cus)
+        if (GEGLU && (p.K < 640 || v3s_choice() >= 2) && v3s_choice() && v3_ok(p, 64, 64) && ((p.M + 255) / 256) * ((p.N + 127) / 128) >= 2 * cus)
             return launch_v3<MODE, GEGLU>(p, st, 2);
         static double fill_k = -1.0;
         if (fill_k < 0) {
