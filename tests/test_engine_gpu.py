@@ -119,3 +119,20 @@ def test_full_width_vs_oracle(full_unet):
     out = full_unet(x.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=1, image_only_indicator=torch.zeros(2, 1, device=DEV))
     rel, cos = rel_cos(out, ref)
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
+
+
+def test_full_width_decoder_vs_oracle():
+    """Full-width VideoDecoder (128 base channels, 64 x 64 latent -> 512 x 512) against the fp32 CPU oracle on one frame."""
+    from oracle import sgm_oracle as O
+    from v3d_amd import synth
+    from v3d_amd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    with torch.device(DEV):
+        dec = VideoDecoder(**synth.decoder_config(128)).eval()
+    synth.init_module_fast(dec, seed=2)
+    z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5))
+    sd = {k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
+    ref = O.decoder_forward(sd, synth.decoder_config(128), z, 1)
+    out = dec(z.to(DEV), timesteps=1)
+    assert out.shape == (1, 3, 512, 512)
+    rel, cos = rel_cos(out, ref)
+    assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
