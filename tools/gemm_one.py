@@ -1,4 +1,4 @@
-"""Run a few v3d_gemm shapes a handful of times (for rocprofv3 --pmc passes)."""
+"""Run a few v3d_gemm shapes a handful of times (for rocprofv3 --pmc passes).  env SHAPES=sq,conv,ff2,geglu"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,8 +24,8 @@ def run(M, N, K, geglu=False, conv=None, res=False, reps=3):
     for _ in range(reps):
         hip.gemm(call)
     torch.cuda.synchronize()
-run(36 * 4096, 2560, 320, geglu=True)
-run(36 * 4096, 320, 320)
-run(36 * 4096, 320, 1280, res=True)
-run(4096, 4096, 4096)
-run(0, 320, 320, conv=(36, 64, 64))
+sel = os.environ.get("SHAPES", "sq,conv,ff2,geglu").split(",")
+if "geglu" in sel: run(36 * 4096, 2560, 320, geglu=True)
+if "ff2" in sel: run(36 * 4096, 320, 1280, res=True)
+if "sq" in sel: run(4096, 4096, 4096)
+if "conv" in sel: run(0, 320, 320, conv=(36, 64, 64))
