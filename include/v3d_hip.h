@@ -166,6 +166,10 @@ int v3d_cfg_combine(const float* x, const float* scale, float* out, int64_t n, i
 /* Euler step (sampling.py:96-110, sampling_utils.py:34-35): d = (x - den)/sigma[n]; out = x + (next[n]-sigma[n])*d */
 int v3d_euler_step(const float* x, const float* den, const float* sigma, const float* next_sigma, float* out,
                    int64_t n, int64_t chw, v3d_stream_t stream);
+/* Heun correction (HeunEDMSampler.possible_correction_step, sampling.py:221-237; to_d: sampling_utils.py:34-35):
+ * d = (x - den)/sigma[n]; d_new = (euler - den2)/next[n]; out = next[n] > 0 ? x + (next[n]-sigma[n]) * (d + d_new)/2 : euler */
+int v3d_heun_step(const float* x, const float* den, const float* euler, const float* den2, const float* sigma,
+                  const float* next_sigma, float* out, int64_t n, int64_t chw, v3d_stream_t stream);
 /* x[n][...] *= s  (sampling.py:50) ; generic y = a*x + b on fp32 */
 int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream);
 /* AlphaBlender coefficients (diffusionmodules/util.py:341-369): for mixer i with alpha_i = sigmoid(mix_factor_i)

@@ -80,6 +80,20 @@ def main():
 
     out["sample_z"] = sampler(den, noise.clone(), cond=c, uc=uc).clone()
 
+    # ---- the other sampler / guiders behind the same API ----
+    disc = {"target": "sgm.modules.diffusionmodules.discretizer.EDMDiscretization", "params": {"sigma_max": p["sigma_max"]}}
+    heun = m["sampling"].HeunEDMSampler(
+        discretization_config=disc, num_steps=p["steps"],
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.CentralPredictionGuider",
+                       "params": {"max_scale": p["max_scale"], "min_scale": p["min_scale"], "num_frames": T}},
+        device="cpu")
+    out["sample_z_heun_central"] = heun(den, noise.clone(), cond=c, uc=uc).clone()
+    vanilla = m["sampling"].EulerEDMSampler(
+        discretization_config=disc, num_steps=p["steps"],
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": p["max_scale"]}},
+        device="cpu")
+    out["sample_z_euler_vanilla"] = vanilla(den, noise.clone(), cond=c, uc=uc).clone()
+
     # ---- VideoDecoder ----
     dcfg = synth.decoder_config(p["vae_ch"])
     dec = m["temporal_ae"].VideoDecoder(**dcfg).eval()

@@ -202,6 +202,13 @@ class EmulOps(OpsBase):
         d = (x - den) / sigma.reshape(shp)
         return x + (next_sigma - sigma).reshape(shp) * d
 
+    def heun_step(self, x, den, euler, den2, sigma, next_sigma):
+        shp = (x.shape[0],) + (1,) * (x.dim() - 1)
+        sg, nx = sigma.reshape(shp), next_sigma.reshape(shp)
+        d = (x - den) / sg
+        dn = (euler - den2) / torch.where(nx > 0, nx, torch.ones_like(nx))
+        return torch.where(nx > 0, x + (nx - sg) * ((d + dn) * 0.5), euler)
+
     def axpb_f32(self, x, a, b=0.0, out=None):
         r = x * a + b
         if out is not None:

@@ -223,28 +223,58 @@ def denoise(net, x: torch.Tensor, sigma: torch.Tensor, cond: dict) -> torch.Tens
     return net(xin, c_noise, cond["crossattn"], cond["vector"]) * c_out + x * c_skip
 
 
-def sample_euler_edm(net, x: torch.Tensor, c: dict, uc: dict, num_steps: int, T: int, min_scale: float, max_scale: float,
-                     sigma_max: float = 700.0, return_all: bool = False):
-    """EulerEDMSampler.__call__ with s_churn = 0 and LinearPredictionGuider (sampling.py:44-55,96-133,214-218;
-    guiders.py:78-101; sampling_utils.py:34-35).  `x` is NOT modified in place here (callers pass a copy)."""
+def guider_scale(kind: str, T: int, min_scale: float, max_scale: float) -> torch.Tensor:
+    """Per-frame CFG scale: LinearPredictionGuider (guiders.py:61-76), CentralPredictionGuider (guiders.py:104-118),
+    VanillaCFG (guiders.py:24-31: one scale = max_scale for every frame)."""
+    if kind == "linear":
+        return torch.linspace(min_scale, max_scale, T)
+    if kind == "central":
+        sc = torch.linspace(min_scale, 2 * max_scale, T)
+        sc[T // 2:] = 2 * max_scale - sc[T // 2:]
+        return sc
+    if kind == "vanilla":
+        return torch.full((T,), float(max_scale))
+    raise ValueError(kind)
+
+
+def sample_edm(net, x: torch.Tensor, c: dict, uc: dict, num_steps: int, T: int, min_scale: float, max_scale: float,
+               sigma_max: float = 700.0, return_all: bool = False, guider: str = "linear", heun: bool = False):
+    """EDMSampler.__call__ with s_churn = 0 (sampling.py:44-55,96-133), Euler (214-218) or Heun correction (221-237), and a
+    per-frame-scale CFG guider (guiders.py:24-42,78-101,125-146; sampling_utils.py:34-35).
+    `x` is NOT modified in place here (callers pass a copy)."""
     sigmas = edm_sigmas(num_steps, sigma_max=sigma_max).to(x.device)
     x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     s_in = x.new_ones([x.shape[0]])
-    scale = torch.linspace(min_scale, max_scale, T, device=x.device)
+    scale = guider_scale(guider, T, min_scale, max_scale).to(x.device)
     cond = {k: torch.cat([uc[k], c[k]], dim=0) for k in ("vector", "crossattn", "concat")}   # batch = [uc ; c]
-    traj = []
-    for i in range(num_steps):
-        sig, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
-        den = denoise(net, torch.cat([x, x]), torch.cat([sig, sig]), cond)
+
+    def guided(xx, sg):
+        den = denoise(net, torch.cat([xx, xx]), torch.cat([sg, sg]), cond)
         x_u, x_c = den.chunk(2)
         n = x_u.shape[0]
         sc = scale.repeat(n // T).reshape(n, 1, 1, 1)
-        den = x_u + sc * (x_c - x_u)
+        return x_u + sc * (x_c - x_u)
+
+    traj = []
+    for i in range(num_steps):
+        sig, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
+        den = guided(x, sig)
         d = (x - den) / sig.reshape(-1, 1, 1, 1)
-        x = x + (nxt - sig).reshape(-1, 1, 1, 1) * d
+        dt = (nxt - sig).reshape(-1, 1, 1, 1)
+        euler = x + dt * d
+        if heun and float(nxt.sum()) >= 1e-14:
+            d_new = (euler - guided(euler, nxt)) / nxt.reshape(-1, 1, 1, 1)
+            x = torch.where(nxt.reshape(-1, 1, 1, 1) > 0.0, x + (d + d_new) / 2.0 * dt, euler)
+        else:
+            x = euler
         if return_all:
             traj.append(x.clone())
     return (x, traj) if return_all else x
+
+
+def sample_euler_edm(net, x, c, uc, num_steps, T, min_scale, max_scale, sigma_max: float = 700.0, return_all: bool = False):
+    """EulerEDMSampler x LinearPredictionGuider (the V3D_512 configuration)."""
+    return sample_edm(net, x, c, uc, num_steps, T, min_scale, max_scale, sigma_max, return_all, "linear", False)
 
 
 # ------------------------------------------------------------------------------------------------

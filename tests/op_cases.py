@@ -175,6 +175,11 @@ def case_elementwise(hip, emu, dev, seed=0):
     scale = _rand(g, (T,), F32, 1.0, dev) + 3
     res["cfg_combine"] = compare(hip.cfg_combine(x, scale, T), emu.cfg_combine(x, scale, T))
     res["euler_step"] = compare(hip.euler_step(x, cond, sig, sig * 0.5), emu.euler_step(x, cond, sig, sig * 0.5))
+    nxt = sig * 0.5
+    nxt[::2] = 0.0                      # exercises the "noise level 0 -> keep the Euler step" branch per sample
+    eul = emu.euler_step(x, cond, sig, nxt)
+    den2 = (x * 0.3 + cond * 0.1).contiguous()
+    res["heun_step"] = compare(hip.heun_step(x, cond, eul, den2, sig, nxt), emu.heun_step(x, cond, eul, den2, sig, nxt))
     res["axpb"] = compare(hip.axpb_f32(x, 1.5, -0.25), emu.axpb_f32(x, 1.5, -0.25))
     alpha = torch.sigmoid(_rand(g, (5,), F32, 1.0, dev))
     kind = torch.tensor([0, 1, 0, 1, 1], dtype=torch.int32, device=dev)

@@ -8,7 +8,7 @@ import torch
 
 from conftest import rel_cos
 from oracle.ops_emul import EmulOps
-from tiny import TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs
+from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs
 from v3d_amd.ops import use_backend
 from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
@@ -60,6 +60,22 @@ def test_sampler_loop(golden, exact, tol, cosmin):
         assert rel <= tol and cos >= cosmin, (rel, cos)
         # prepare_sampling_loop scales the CALLER's noise tensor in place, like the reference (sampling.py:50)
         assert torch.allclose(x0, noise * (1 + 700.0 ** 2) ** 0.5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind,key", [kv for kv in SAMPLER_FIXTURES if kv[0] != "euler_linear"])
+def test_other_samplers_and_guiders(golden, kind, key):
+    """HeunEDMSampler x CentralPredictionGuider and EulerEDMSampler x VanillaCFG behind the same plugin API,
+    exact-fp32 emulated kernels against the reference fixtures."""
+    p = TINY
+    T = p["T"]
+    noise, c, uc, *_ = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    with use_backend(EmulOps("cpu", exact=True)):
+        net = build_unet()
+        sampler, den, wr = build_sampler(T, kind=kind), build_denoiser(), OpenAIWrapper(net)
+        extra = {"image_only_indicator": torch.zeros(2, T), "num_video_frames": T}
+        z = sampler(lambda i, s, cc: den(wr, i, s, cc, **extra), noise.clone(), cond=c, uc=uc)
+        rel, cos = rel_cos(z, golden[key])
+        assert rel <= 1e-4 and cos >= 0.99999, (rel, cos)
 
 
 def test_packing_invalidation():

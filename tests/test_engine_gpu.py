@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import rel_cos
-from tiny import TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs, to_dev
+from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs, to_dev
 from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
 pytestmark = pytest.mark.gpu
@@ -45,16 +45,19 @@ def test_decoder_vs_reference_fixture(golden):
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
 
 
-def test_sampler_vs_reference_fixture(golden):
+@pytest.mark.parametrize("kind,key", SAMPLER_FIXTURES)
+def test_sampler_vs_reference_fixture(golden, kind, key):
     p = TINY
     T = p["T"]
     noise, c, uc, *_ = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
     net = build_unet(DEV)
-    sampler, den, wr = build_sampler(T, device=DEV), build_denoiser(), OpenAIWrapper(net)
+    sampler, den, wr = build_sampler(T, device=DEV, kind=kind), build_denoiser(), OpenAIWrapper(net)
     extra = {"image_only_indicator": torch.zeros(2, T, device=DEV), "num_video_frames": T}
     z = sampler(lambda i, s, cc: den(wr, i, s, cc, **extra), noise.to(DEV), cond=to_dev(c, DEV), uc=to_dev(uc, DEV))
-    rel, cos = rel_cos(z, golden["sample_z"])
-    assert cos >= 0.99 and rel <= 0.1, (rel, cos)
+    rel, cos = rel_cos(z, golden[key])
+    # Heun x CentralPredictionGuider runs 6 evaluations with guidance scales up to 2 * max_scale on a random-weight net: bf16
+    # storage alone (the CPU emulator in bf16 mode, no HIP kernel involved) lands at rel 0.12 / cos 0.9964 there
+    assert cos >= 0.99 and rel <= (0.2 if kind == "heun_central" else 0.1), (rel, cos)
 
 
 def test_unet_vs_oracle_other_shapes():

@@ -16,8 +16,8 @@ def _unet_sd():
     return synth.seeded_state_dict(net, TINY["weight_seed"])
 
 
-def _close(a, b):
-    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), f"max abs diff {(a - b).abs().max().item():.3e}"
+def _close(a, b, scale=1.0):
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * max(1.0, scale)), f"max abs diff {(a - b).abs().max().item():.3e}"
 
 
 def test_unet_eval_and_ioi(golden):
@@ -54,6 +54,11 @@ def test_sampler(golden):
     net = lambda x, t, ca, v: O.unet_forward(sd, cfg, x, t, ca, v, T, ioi)
     z = O.sample_euler_edm(net, noise.clone(), c, uc, p["steps"], T, p["min_scale"], p["max_scale"], p["sigma_max"])
     _close(z, golden["sample_z"])
+    # Heun correction x CentralPredictionGuider, Euler x VanillaCFG (fixtures from the reference classes)
+    z = O.sample_edm(net, noise.clone(), c, uc, p["steps"], T, p["min_scale"], p["max_scale"], p["sigma_max"], guider="central", heun=True)
+    _close(z, golden["sample_z_heun_central"], scale=golden["sample_z_heun_central"].abs().max().item())
+    z = O.sample_edm(net, noise.clone(), c, uc, p["steps"], T, p["min_scale"], p["max_scale"], p["sigma_max"], guider="vanilla")
+    _close(z, golden["sample_z_euler_vanilla"])
 
 
 def test_decoder(golden):

@@ -23,15 +23,21 @@ def build_decoder(device="cpu"):
     return dec.to(device).eval()
 
 
-def build_sampler(T, steps=None, device="cpu"):
-    from v3d_amd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+def build_sampler(T, steps=None, device="cpu", kind="euler_linear"):
+    """kind: euler_linear (V3D_512), heun_central, euler_vanilla - the three (sampler, guider) pairs with reference fixtures."""
+    from v3d_amd.sgm.modules.diffusionmodules import sampling
     p = TINY
-    return EulerEDMSampler(
-        discretization_config={"target": P + "discretizer.EDMDiscretization", "params": {"sigma_max": p["sigma_max"]}},
-        num_steps=steps or p["steps"],
-        guider_config={"target": P + "guiders.LinearPredictionGuider",
-                       "params": {"max_scale": p["max_scale"], "min_scale": p["min_scale"], "num_frames": T}},
-        device=device)
+    cls = sampling.HeunEDMSampler if kind.startswith("heun") else sampling.EulerEDMSampler
+    if kind.endswith("vanilla"):
+        guider = {"target": P + "guiders.VanillaCFG", "params": {"scale": p["max_scale"]}}
+    else:
+        name = "CentralPredictionGuider" if kind.endswith("central") else "LinearPredictionGuider"
+        guider = {"target": P + "guiders." + name, "params": {"max_scale": p["max_scale"], "min_scale": p["min_scale"], "num_frames": T}}
+    return cls(discretization_config={"target": P + "discretizer.EDMDiscretization", "params": {"sigma_max": p["sigma_max"]}},
+               num_steps=steps or p["steps"], guider_config=guider, device=device)
+
+
+SAMPLER_FIXTURES = [("euler_linear", "sample_z"), ("heun_central", "sample_z_heun_central"), ("euler_vanilla", "sample_z_euler_vanilla")]
 
 
 def build_denoiser():

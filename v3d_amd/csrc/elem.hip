@@ -98,6 +98,24 @@ __global__ void euler_step_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+__global__ void heun_step_kernel(const float* __restrict__ x, const float* __restrict__ den, const float* __restrict__ euler,
+                                 const float* __restrict__ den2, const float* __restrict__ sigma, const float* __restrict__ next_sigma,
+                                 float* __restrict__ out, long long n, long long chw) {
+    const long long total = n * chw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / chw;
+        const float sg = sigma[img], nx = next_sigma[img];
+        const float e = euler[i];
+        if (nx > 0.f) {
+            const float d = (x[i] - den[i]) / sg;
+            const float dn = (e - den2[i]) / nx;
+            out[i] = x[i] + (nx - sg) * ((d + dn) * 0.5f);
+        } else {
+            out[i] = e;
+        }
+    }
+}
+
 __global__ void axpb_kernel(const float* __restrict__ x, float a, float b, float* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = a * x[i] + b;
 }
@@ -218,6 +236,13 @@ extern "C" int v3d_euler_step(const float* x, const float* den, const float* sig
     V3D_REQUIRE(x && den && sigma && next_sigma && out && n > 0 && chw > 0, "v3d_euler_step: bad args");
     hipLaunchKernelGGL(euler_step_kernel, dim3(nblocks(n * chw)), dim3(256), 0, ST, x, den, sigma, next_sigma, out, (long long)n, (long long)chw);
     return v3d_check_launch("v3d_euler_step");
+}
+
+extern "C" int v3d_heun_step(const float* x, const float* den, const float* euler, const float* den2, const float* sigma,
+                             const float* next_sigma, float* out, int64_t n, int64_t chw, v3d_stream_t stream) {
+    V3D_REQUIRE(x && den && euler && den2 && sigma && next_sigma && out && n > 0 && chw > 0, "v3d_heun_step: bad args");
+    hipLaunchKernelGGL(heun_step_kernel, dim3(nblocks(n * chw)), dim3(256), 0, ST, x, den, euler, den2, sigma, next_sigma, out, (long long)n, (long long)chw);
+    return v3d_check_launch("v3d_heun_step");
 }
 
 extern "C" int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream) {

@@ -61,6 +61,7 @@ SIGNATURES = {
     "v3d_denoise_combine": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "v3d_cfg_combine": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "v3d_euler_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "v3d_heun_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_axpb_f32": (c_i32, [c_vp, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "v3d_blend_coefs": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
@@ -299,6 +300,16 @@ class HipOps(OpsBase):
         n = x.shape[0]
         self._check(self.lib.v3d_euler_step(x.data_ptr(), den.data_ptr(), sigma.data_ptr(), next_sigma.data_ptr(), out.data_ptr(),
                                             n, x.numel() // n, self._stream()), "v3d_euler_step")
+        return out
+
+    def heun_step(self, x, den, euler, den2, sigma, next_sigma):
+        f32 = torch.float32
+        for t, nm in ((x, "x"), (den, "den"), (euler, "euler"), (den2, "den2"), (sigma, "sigma"), (next_sigma, "next")):
+            self._req_c(t, f32, f"heun.{nm}")
+        out = torch.empty_like(x)
+        n = x.shape[0]
+        self._check(self.lib.v3d_heun_step(x.data_ptr(), den.data_ptr(), euler.data_ptr(), den2.data_ptr(), sigma.data_ptr(),
+                                           next_sigma.data_ptr(), out.data_ptr(), n, x.numel() // n, self._stream()), "v3d_heun_step")
         return out
 
     def axpb_f32(self, x, a, b=0.0, out=None):

@@ -1,4 +1,4 @@
-"""Guiders (reference: sgm/modules/diffusionmodules/guiders.py:13-101)."""
+"""Guiders (reference: sgm/modules/diffusionmodules/guiders.py:13-146)."""
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
@@ -80,3 +80,15 @@ class LinearPredictionGuider(Guider):
     def prepare_inputs(self, x, s, c, uc):
         keys = ["vector", "crossattn", "concat"] + self.additional_cond_keys
         return torch.cat([x] * 2), torch.cat([s] * 2), _cat_cond(c, uc, keys)
+
+
+class CentralPredictionGuider(LinearPredictionGuider):
+    """Triangular per-frame scale peaking at the central frame (guiders.py:104-146): linspace(min, 2 max, T) mirrored over the
+    second half.  Same kernel as the linear guider - only the scale vector differs."""
+
+    def __init__(self, max_scale: float, num_frames: int, min_scale: float = 1.0,
+                 additional_cond_keys: Optional[Union[List[str], str]] = None):
+        super().__init__(max_scale, num_frames, min_scale, additional_cond_keys)
+        scale = torch.linspace(min_scale, 2 * max_scale, num_frames)
+        scale[num_frames // 2:] = 2 * max_scale - scale[num_frames // 2:]
+        self.scale = scale.unsqueeze(0)

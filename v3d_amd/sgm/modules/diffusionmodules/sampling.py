@@ -72,9 +72,15 @@ class EDMSampler(SingleStepDiffusionSampler):
             x = x + eps * ((sigma_hat ** 2 - sigma ** 2) ** 0.5).reshape((-1,) + (1,) * (x.dim() - 1))
         denoised = self.denoise(x, denoiser, sigma_hat, cond, uc)
         # d = (x - denoised) / sigma_hat ; euler: x + (next_sigma - sigma_hat) d   — one fused kernel
-        euler = ops.euler_step(x.contiguous(), denoised.contiguous(), sigma_hat, next_sigma)
-        # reference signature (euler_step, x, d, dt, next_sigma, ...): d and dt are only materialised by samplers that need them
-        return self.possible_correction_step(euler, x, None, None, next_sigma, denoiser, cond, uc)
+        x = x.contiguous()
+        denoised = denoised.contiguous()
+        euler = ops.euler_step(x, denoised, sigma_hat, next_sigma)
+        # reference signature (euler_step, x, d, dt, next_sigma, ...).  d and dt are never materialised: a sampler that needs them
+        # (Heun) gets the tensors they are made of in `_step_ctx` and fuses its update into one kernel
+        self._step_ctx = (denoised, sigma_hat)
+        out = self.possible_correction_step(euler, x, None, None, next_sigma, denoiser, cond, uc)
+        self._step_ctx = None
+        return out
 
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
         ops = get_ops()
@@ -82,6 +88,7 @@ class EDMSampler(SingleStepDiffusionSampler):
         sig = [float(s) for s in sigmas]
         for i in self.get_sigma_gen(num_sigmas):
             gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sig[i] <= self.s_tmax else 0.0
+            self._next_sigma_is_zero = sig[i + 1] < 1e-14 / max(1, x.shape[0])   # host copy of `torch.sum(next_sigma) < 1e-14`
             x = self.sampler_step(ops.axpb_f32(s_in, sig[i], 0.0), ops.axpb_f32(s_in, sig[i + 1], 0.0),
                                   denoiser, x, cond, uc, gamma)
         return x
@@ -90,3 +97,16 @@ class EDMSampler(SingleStepDiffusionSampler):
 class EulerEDMSampler(EDMSampler):
     def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
         return euler_step
+
+
+class HeunEDMSampler(EDMSampler):
+    """2nd-order correction (sampling.py:221-237): one more guided evaluation at (euler_step, next_sigma), then
+    x + dt (d + d_new) / 2 where next_sigma > 0.  The "all noise levels are 0 -> skip the evaluation" test of the reference
+    (`torch.sum(next_sigma) < 1e-14`, a device sync there) is decided on the host copy of the sigma schedule."""
+
+    def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
+        if getattr(self, "_next_sigma_is_zero", False):
+            return euler_step
+        denoised, sigma_hat = self._step_ctx
+        denoised2 = self.denoise(euler_step, denoiser, next_sigma, cond, uc)
+        return get_ops().heun_step(x, denoised, euler_step, denoised2.contiguous(), sigma_hat, next_sigma)
