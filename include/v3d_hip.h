@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 1
+#define V3D_ABI_VERSION 2
 #define V3D_GN_SLOTS 32
 
 typedef void* v3d_stream_t; /* hipStream_t */
@@ -87,6 +87,8 @@ typedef struct v3d_gemm_args {
     int32_t T, tmin, tmax;                    /* CONVT3 (S = rows per frame) */
     int64_t S;
     int32_t batch;                            /* >= 1; grid.y */
+    int32_t pad_mode;                         /* CONV3X3 (ABI 2): 0 = one zero pixel on every side (Conv2d padding=1); 1 = right/bottom only,
+                                                 F.pad(x,(0,1,0,1)) + padding=0: the VAE encoder's Downsample (diffusionmodules/model.py:74-91) */
     int64_t sA, sW, sO;                       /* element strides between batches (A, W, out) */
 } v3d_gemm_args;
 

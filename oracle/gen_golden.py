@@ -104,6 +104,14 @@ def main():
     out["dec_out"] = dec(z, timesteps=T).clone()
     out["dec_out_T1"] = dec(z[:1], timesteps=1).clone()
 
+    # ---- VAE Encoder (moments) on a 64 x 48 image batch, + the AutoencodingEngine-style mode() ----
+    ecfg = synth.encoder_config(p["vae_ch"])
+    enc = m["model"].Encoder(**ecfg).eval()
+    enc.load_state_dict(synth.seeded_state_dict(enc, p["weight_seed"] + 2), strict=True)
+    g = torch.Generator().manual_seed(p["seed"] + 4)
+    img = torch.rand(2, 3, 64, 48, generator=g) * 2.0 - 1.0
+    out["enc_moments"] = enc(img).clone()
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     torch.save(out, OUT)
     for k, v in out.items():

@@ -42,7 +42,10 @@ class EmulOps(OpsBase):
             if g.up == 2:
                 x = F.interpolate(x, scale_factor=2, mode="nearest")
             w = W.float().reshape(3, 3, N, K).permute(2, 3, 0, 1)
-            y = F.conv2d(x, w, stride=g.stride, padding=1)
+            if g.pad_mode:
+                y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=g.stride, padding=0)
+            else:
+                y = F.conv2d(x, w, stride=g.stride, padding=1)
             assert y.shape[2] == g.Hout and y.shape[3] == g.Wout, (y.shape, g.Hout, g.Wout)
             return y.permute(0, 2, 3, 1).reshape(M, N)
         if g.mode == GEMM_CONVT3:

@@ -331,3 +331,41 @@ def decode_first_stage(sd: SD, cfg: dict, z: torch.Tensor, scale_factor: float, 
     z = z / scale_factor
     outs = [decoder_forward(sd, cfg, z[i:i + decoding_t], len(z[i:i + decoding_t])) for i in range(0, z.shape[0], decoding_t)]
     return torch.cat(outs, dim=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# VAE encoder + regulariser
+# ------------------------------------------------------------------------------------------------
+def resnet2d(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """ResnetBlock.forward with temb = None (model.py:131-151)."""
+    h = F.conv2d(F.silu(_gn(sd, p + ".norm1", x, 1e-6)), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    h = F.conv2d(F.silu(_gn(sd, p + ".norm2", h, 1e-6)), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    if p + ".nin_shortcut.weight" in sd:
+        x = F.conv2d(x, sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"])
+    return x + h
+
+
+def encoder_forward(sd: SD, cfg: dict, x: torch.Tensor) -> torch.Tensor:
+    """Encoder.forward (model.py:575-601): conv_in, per level num_res_blocks ResnetBlocks (+ AttnBlock where the resolution is
+    in attn_resolutions), Downsample = F.pad(0,1,0,1) + conv stride 2 padding 0 (model.py:74-91), mid, GN + swish, conv_out."""
+    nlev, nres = len(cfg["ch_mult"]), cfg["num_res_blocks"]
+    res = cfg["resolution"]
+    h = F.conv2d(x, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    for lvl in range(nlev):
+        for i in range(nres):
+            h = resnet2d(sd, f"down.{lvl}.block.{i}", h)
+            if res in cfg["attn_resolutions"]:
+                h = vae_attn(sd, f"down.{lvl}.attn.{i}", h)
+        if lvl != nlev - 1:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"down.{lvl}.downsample.conv.weight"], sd[f"down.{lvl}.downsample.conv.bias"], stride=2)
+            res //= 2
+    h = resnet2d(sd, "mid.block_1", h)
+    h = vae_attn(sd, "mid.attn_1", h)
+    h = resnet2d(sd, "mid.block_2", h)
+    h = F.silu(_gn(sd, "norm_out", h, 1e-6))
+    return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+def gaussian_mode(moments: torch.Tensor) -> torch.Tensor:
+    """DiagonalGaussianRegularizer(sample=False) -> posterior.mode() (regularizers/__init__.py:19-31; distributions.py:25-41)."""
+    return torch.chunk(moments, 2, dim=1)[0]

@@ -72,7 +72,8 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
                decoding_t: int = 24, device: str = "cuda", output_folder: Optional[str] = None, noise: torch.Tensor = None,
                save: bool = False, cached_model: Any = None, border_ratio: float = 0.3, min_guidance_scale: float = 3.5,
                max_guidance_scale: float = 3.5, sigma_max: float = None, ignore_alpha: bool = False, *, config=None,
-               cond_frames: torch.Tensor = None, cond_frames_without_noise: torch.Tensor = None, synthetic: bool = False,
+               cond_frames: torch.Tensor = None, cond_frames_without_noise: torch.Tensor = None, image: torch.Tensor = None,
+               synthetic: bool = False,
                height: int = 512, width: int = 512, model_channels: int = 320, vae_ch: int = 128):
     """Returns (frames uint8 [T, H, W, 3] on the host, model).  Keyword arguments up to `ignore_alpha` are the reference's."""
     num_frames = 18 if num_frames is None else num_frames       # the reference reads it from the guider config (18)
@@ -92,14 +93,21 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
     torch.manual_seed(seed)
     F = 8
     h, w = height // F, width // F
+    if cond_frames is None and image is not None:
+        # native VAE encode of the conditioning view (reference: `ae_model.encode(image)`, V3D_512.py:239): image [1,3,H,W] in [-1,1]
+        if checkpoint_path is None and synthetic and cached_model is None:
+            synth.init_module_fast(model.first_stage_model.encoder, seed=3)
+        cond_frames = model.first_stage_model.encode(image.to(device).float())
     if cond_frames is None or cond_frames_without_noise is None:
         if not synthetic:
             raise SystemExit(
-                f"image front-end (matting / recentering / CLIP / VAE-encode of {input_path}) is not part of this build: pass "
-                "cond_frames [1,4,H/8,W/8] and cond_frames_without_noise [1,1,1024] tensors, or --synthetic")
+                f"image front-end (matting / recentering / OpenCLIP embedding of {input_path}) is not part of this build: pass `image` "
+                "(or cond_frames [1,4,H/8,W/8]) and cond_frames_without_noise [1,1,1024] tensors, or --synthetic")
         g = torch.Generator().manual_seed(seed)
-        cond_frames_without_noise = torch.randn(1, 1, 1024, generator=g).to(device)
-        cond_frames = torch.randn(1, 4, h, w, generator=g).to(device)
+        if cond_frames_without_noise is None:
+            cond_frames_without_noise = torch.randn(1, 1, 1024, generator=g).to(device)
+        if cond_frames is None:
+            cond_frames = torch.randn(1, 4, h, w, generator=g).to(device)
     cond_frames = cond_frames.to(device) + cond_aug * torch.randn_like(cond_frames.to(device))
     value_dict = dict(motion_bucket_id=motion_bucket_id, fps_id=fps_id, cond_aug=cond_aug, cond_frames=cond_frames,
                       cond_frames_without_noise=cond_frames_without_noise.to(device))
@@ -154,9 +162,16 @@ def main():
     ap.add_argument("--sigma_max", type=float, default=None)
     ap.add_argument("--synthetic", action="store_true")
     a = ap.parse_args()
+    image = None
+    if os.path.isfile(a.input_path):
+        # plain load + resize to 512 x 512 -> [-1, 1]; the reference's matting / recentering (rembg, kiui) stays outside this build
+        from PIL import Image
+        import numpy as np
+        im = Image.open(a.input_path).convert("RGB").resize((512, 512))
+        image = torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1)[None].float() / 127.5 - 1.0
     frames, _ = sample_one(a.input_path, a.checkpoint_path, a.num_frames, a.num_steps, a.fps_id, a.motion_bucket_id, a.cond_aug, a.seed,
                            a.decoding_t, a.device, a.output_folder, save=a.save, min_guidance_scale=a.min_guidance_scale,
-                           max_guidance_scale=a.max_guidance_scale, sigma_max=a.sigma_max, config=a.config, synthetic=a.synthetic)
+                           max_guidance_scale=a.max_guidance_scale, sigma_max=a.sigma_max, config=a.config, synthetic=a.synthetic, image=image)
     print("frames", frames.shape, frames.dtype, "mean", float(frames.mean()))
 
 

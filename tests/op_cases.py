@@ -34,17 +34,18 @@ def compare(a: torch.Tensor, b: torch.Tensor):
 
 # ------------------------------------------------------------------------------------------------
 def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=True, add=False, res=0, coef=False,
-              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True):
+              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0):
     g = torch.Generator().manual_seed(seed)
     kw = {}
     n_out = N // 2 if geglu else N
     taps = {GEMM_LINEAR: 1, GEMM_CONV3X3: 9, GEMM_CONVT3: 3}[mode]
     if mode == GEMM_CONV3X3:
         n_img, Hin, Win, stride, up = conv
-        Hout, Wout = (Hin * up + 2 - 3) // stride + 1, (Win * up + 2 - 3) // stride + 1
+        ptot = 1 if pad_mode else 2      # pad_mode 1: zero pixels on the right / bottom only (VAE encoder Downsample)
+        Hout, Wout = (Hin * up + ptot - 3) // stride + 1, (Win * up + ptot - 3) // stride + 1
         a_rows = n_img * Hin * Win
         M = n_img * Hout * Wout
-        kw.update(Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, up=up)
+        kw.update(Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, up=up, pad_mode=pad_mode)
     elif mode == GEMM_CONVT3:
         B, T, S, halo, tmin, tmax = convt
         M = B * T * S
@@ -221,6 +222,8 @@ def all_cases(full: bool = True):
         ("conv3x3_odd_hw", case_gemm, dict(M=0, N=40, K=24, mode=C3, conv=(3, 7, 5, 1, 1), add=True, res=1), TOL_BF16),
         ("conv3x3_stride2", case_gemm, dict(M=0, N=64, K=64, mode=C3, conv=(2, 16, 16, 2, 1)), TOL_BF16),
         ("conv3x3_up2", case_gemm, dict(M=0, N=64, K=64, mode=C3, conv=(2, 8, 8, 1, 2)), TOL_BF16),
+        ("conv3x3_stride2_asym_pad", case_gemm, dict(M=0, N=64, K=64, mode=C3, conv=(2, 16, 12, 2, 1), pad_mode=1), TOL_BF16),
+        ("conv3x3_stride2_asym_pad_big", case_gemm, dict(M=0, N=256, K=128, mode=C3, conv=(4, 64, 64, 2, 1), pad_mode=1, res=1), TOL_BF16),
         ("conv3x3_k8", case_gemm, dict(M=0, N=320, K=8, mode=C3, conv=(2, 16, 16, 1, 1)), TOL_BF16),
         ("convt3_small", case_gemm, dict(M=0, N=64, K=64, mode=CT, convt=(2, 5, 16, 0, 0, 4), res=1, coef=True), TOL_BF16),
         ("convt3_T1", case_gemm, dict(M=0, N=64, K=64, mode=CT, convt=(3, 1, 16, 0, 0, 0)), TOL_BF16),

@@ -88,3 +88,14 @@ def test_packing_invalidation():
         net.packed()
         net.float()
         assert net._packed is None
+
+
+@pytest.mark.parametrize("exact,tol,cosmin", MODES)
+def test_encoder(golden, exact, tol, cosmin):
+    """the product Encoder (engine wiring incl. the asymmetric-pad stride-2 Downsample) on emulated kernels."""
+    from tiny import build_encoder, encoder_image
+    with use_backend(EmulOps("cpu", exact=exact)):
+        out = build_encoder()(encoder_image())
+        assert out.shape == golden["enc_moments"].shape
+        rel, cos = rel_cos(out, golden["enc_moments"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)

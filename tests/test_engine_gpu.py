@@ -139,3 +139,11 @@ def test_full_width_decoder_vs_oracle():
     assert out.shape == (1, 3, 512, 512)
     rel, cos = rel_cos(out, ref)
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
+
+
+def test_encoder_vs_reference_fixture(golden):
+    """VAE Encoder on the HIP kernels (asymmetric-pad stride-2 convs = pad_mode 1) vs the reference fixture."""
+    from tiny import build_encoder, encoder_image
+    out = build_encoder(DEV)(encoder_image().to(DEV))
+    rel, cos = rel_cos(out, golden["enc_moments"])
+    assert rel <= 4e-2 and cos >= 0.999, (rel, cos)

@@ -75,6 +75,14 @@ def test_decoder(golden):
     assert (chunked - golden["dec_out"]).abs().max() > 1e-2
 
 
+def test_encoder(golden):
+    """Encoder restatement == reference Encoder on the same seeded weights / image batch."""
+    from tiny import build_encoder, encoder_image
+    enc = build_encoder()
+    sd = {k: v.float() for k, v in enc.state_dict().items()}
+    _close(O.encoder_forward(sd, synth.encoder_config(TINY["vae_ch"]), encoder_image()), golden["enc_moments"])
+
+
 def test_sigma_schedule():
     s = O.edm_sigmas(25, sigma_max=700.0)
     assert s.shape == (26,) and abs(s[0].item() - 700.0) < 1e-3 and abs(s[24].item() - 0.002) < 1e-6 and s[25] == 0

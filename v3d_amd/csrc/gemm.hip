@@ -46,6 +46,7 @@ struct GP {
     long long a_row0;
     unsigned a_bytes, w_bytes;
     int Hin, Win, Hout, Wout, stride, upshift;
+    int pad_lo;          // zero pixels before the first row / column (1, or 0 for the asymmetric right/bottom padding)
     int T, tmin, tmax;
     long long S;
     long long sA, sW, sO;
@@ -89,8 +90,8 @@ struct RowInfo<V3D_GEMM_CONV3X3> {
         int oy = rem / p.Wout;
         int ox = rem - oy * p.Wout;
         base = img * (long long)p.Hin * p.Win;
-        iy0 = oy * p.stride - 1;
-        ix0 = ox * p.stride - 1;
+        iy0 = oy * p.stride - p.pad_lo;
+        ix0 = ox * p.stride - p.pad_lo;
     }
     __device__ bool tap(const GP& p, int t, long long& s) const {
         int ky = t / 3, kx = t - ky * 3;
@@ -1206,6 +1207,7 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     p.a_row0 = a->a_row0; p.a_bytes = (unsigned)a_bytes; p.w_bytes = (unsigned)w_bytes;
     p.Hin = a->Hin; p.Win = a->Win; p.Hout = a->Hout; p.Wout = a->Wout; p.stride = a->stride;
     p.upshift = 0;
+    p.pad_lo = 1;
     p.T = a->T; p.tmin = a->tmin; p.tmax = a->tmax; p.S = a->S;
     p.sA = a->sA; p.sW = a->sW; p.sO = a->sO;
     p.mt = p.nt = 0;
@@ -1222,7 +1224,9 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
             V3D_REQUIRE(a->stride == 1 || a->stride == 2, "v3d_gemm: stride must be 1 or 2");
             V3D_REQUIRE(a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0, "v3d_gemm: bad conv geometry");
             V3D_REQUIRE(a->M % ((long long)a->Hout * a->Wout) == 0, "v3d_gemm: M must be n_img*Hout*Wout");
+            V3D_REQUIRE(a->pad_mode == 0 || a->pad_mode == 1, "v3d_gemm: pad_mode must be 0 or 1");
             p.upshift = a->up - 1;
+            p.pad_lo = a->pad_mode ? 0 : 1;
             return dispatch<V3D_GEMM_CONV3X3, false>(p, a->batch, st);
         case V3D_GEMM_CONVT3:
             V3D_REQUIRE(a->T > 0 && a->S > 0, "v3d_gemm: convt3 needs T,S");

@@ -363,3 +363,49 @@ def pack_vae_decoder(dec) -> VAEPack:
                    conv_in=pack_conv3x3(dec.conv_in), mid=mid, up=up, norm_out=pack_norm(dec.norm_out),
                    conv_out=pack_conv3x3(co), tmix_w=_f(tw.reshape(tw.shape[0], tw.shape[1], 3)), tmix_b=_f(co.time_mix_conv.bias),
                    out_ch=co.weight.shape[0])
+
+
+# ---- VAE encoder ---------------------------------------------------------------------------------------------------
+
+@dataclass
+class VAEEncPack:
+    device: torch.device
+    in_ch: int
+    in_pad: int
+    conv_in: tuple
+    down: List[dict]                 # per level: {"blocks": [ResPack], "attn": [AttnPack | None], "downsample": (w, b) | None}
+    mid: list
+    norm_out: tuple
+    conv_out: tuple                  # conv3x3 block_in -> 2 * z_channels (fp32 output)
+    out_ch: int
+
+
+def pack_resnet2d(rb) -> ResPack:
+    """Plain 2-D ResnetBlock of the VAE encoder (model.py:94-151, temb_channels = 0)."""
+    p = ResPack(cin=rb.in_channels, cout=rb.out_channels, split=None)
+    p.gn1 = pack_norm(rb.norm1)
+    p.w1, p.b1 = pack_conv3x3(rb.conv1)
+    p.gn2 = pack_norm(rb.norm2)
+    p.w2, p.b2 = pack_conv3x3(rb.conv2)
+    if rb.in_channels != rb.out_channels:
+        p.skip_w, p.skip_b = pack_conv1x1(rb.nin_shortcut)
+    return p
+
+
+def _pack_attnblock(a) -> AttnPack:
+    wv, bv = pack_conv1x1(a.v)
+    return AttnPack(C=a.in_channels, norm=pack_norm(a.norm), wq=pack_conv1x1(a.q), wk=pack_conv1x1(a.k), wv=wv, bv=bv,
+                    proj=pack_conv1x1(a.proj_out))
+
+
+def pack_vae_encoder(enc) -> VAEEncPack:
+    down = []
+    for lvl in enc.down:
+        d = {"blocks": [pack_resnet2d(b) for b in lvl.block], "attn": [_pack_attnblock(a) for a in lvl.attn], "downsample": None}
+        if hasattr(lvl, "downsample"):
+            d["downsample"] = pack_conv3x3(lvl.downsample.conv)
+        down.append(d)
+    mid = [("res", pack_resnet2d(enc.mid.block_1)), ("attn", _pack_attnblock(enc.mid.attn_1)), ("res", pack_resnet2d(enc.mid.block_2))]
+    cin = enc.conv_in.weight.shape[1]
+    return VAEEncPack(device=enc.conv_in.weight.device, in_ch=cin, in_pad=round_up(cin, 8), conv_in=pack_conv3x3(enc.conv_in), down=down,
+                      mid=mid, norm_out=pack_norm(enc.norm_out), conv_out=pack_conv3x3(enc.conv_out), out_ch=enc.conv_out.weight.shape[0])

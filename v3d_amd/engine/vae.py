@@ -16,8 +16,8 @@ from __future__ import annotations
 import torch
 
 from ..ops import GemmCall, get_ops
-from .blocks import Env, Geo, vae_resblock
-from .packing import AttnPack, VAEPack
+from .blocks import Env, Geo, res_spatial, vae_resblock
+from .packing import AttnPack, VAEEncPack, VAEPack
 
 F32 = torch.float32
 
@@ -68,3 +68,32 @@ def run_decoder(pk: VAEPack, z: torch.Tensor, T: int, shard=None) -> torch.Tenso
     else:
         out = shard.tmix_small(ops, y, pk.tmix_w, pk.tmix_b, g, pk.out_ch)
     return out.view(g.n, pk.out_ch, g.H, g.W)
+
+
+def run_encoder(pk: VAEEncPack, x: torch.Tensor) -> torch.Tensor:
+    """VAE Encoder (model.py:575-601): x [n, in_ch, H, W] fp32 -> moments [n, 2 * z_channels, H/8, W/8] fp32 (NCHW, like
+    the reference).  conv_in -> per level {2-D ResnetBlocks (+ AttnBlocks), Downsample = zero pad right/bottom + 3x3 stride 2
+    (model.py:74-91: `pad_mode = 1` of v3d_gemm)} -> mid (ResnetBlock, AttnBlock, ResnetBlock) -> GroupNorm + swish -> conv_out.
+    Same kernels, layout and precision policy as the decoder."""
+    ops = get_ops()
+    n, _, H, W = x.shape
+    env = Env(ops=ops, shard=None)
+    g = Geo(n=n, B=n, T=1, H=H, W=W)
+    h = ops.nchw_to_nhwc_bf16(x.float().contiguous(), 1.0, pk.in_pad)
+    h = ops.conv3x3(h, pk.conv_in[0], pk.conv_in[1], n, H, W)
+    for lvl in pk.down:
+        for i, p in enumerate(lvl["blocks"]):
+            h = res_spatial(env, g, p, h, None)
+            if lvl["attn"]:
+                h = run_vae_attn(env, g, lvl["attn"][i], h)
+        ds = lvl["downsample"]
+        if ds is not None:
+            assert g.H % 2 == 0 and g.W % 2 == 0, "VAE Downsample expects even feature maps"
+            h = ops.conv3x3(h, ds[0], ds[1], g.n, g.H, g.W, stride=2, pad_mode=1)
+            g = Geo(n=g.n, B=g.B, T=1, H=g.H // 2, W=g.W // 2)
+    for kind, p in pk.mid:
+        h = res_spatial(env, g, p, h, None) if kind == "res" else run_vae_attn(env, g, p, h)
+    ga, be, eps = pk.norm_out
+    h = ops.groupnorm(h, None, ga, be, g.n, g.S, eps=eps, silu=True)
+    y = ops.conv3x3(h, pk.conv_out[0], pk.conv_out[1], g.n, g.H, g.W, out_dtype=F32)      # [n * S, out_ch] fp32
+    return y.view(g.n, g.H, g.W, pk.out_ch).permute(0, 3, 1, 2).contiguous()

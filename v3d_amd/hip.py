@@ -16,7 +16,7 @@ from .ops import GemmCall, OpsBase
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libv3d_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i64, c_i32, c_f32, c_f64, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_void_p
 
@@ -34,7 +34,7 @@ class _GemmArgs(C.Structure):
         ("Hin", c_i32), ("Win", c_i32), ("Hout", c_i32), ("Wout", c_i32), ("stride", c_i32), ("up", c_i32),
         ("T", c_i32), ("tmin", c_i32), ("tmax", c_i32),
         ("S", c_i64),
-        ("batch", c_i32),
+        ("batch", c_i32), ("pad_mode", c_i32),
         ("sA", c_i64), ("sW", c_i64), ("sO", c_i64),
     ]
 
@@ -166,6 +166,7 @@ class HipOps(OpsBase):
         a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up = g.Hin, g.Win, g.Hout, g.Wout, g.stride, g.up
         a.T, a.tmin, a.tmax, a.S = g.T, g.tmin, g.tmax, g.S
         a.batch = g.batch
+        a.pad_mode = g.pad_mode
         if g.batch > 1:
             if g.mode != 0:
                 raise RuntimeError("gemm: batching is only defined for LINEAR mode")

@@ -51,6 +51,7 @@ class GemmCall:
     Wout: int = 0
     stride: int = 1
     up: int = 1
+    pad_mode: int = 0        # 0: one zero pixel on every side; 1: right/bottom only (F.pad(0,1,0,1) + padding=0)
     # convt3 geometry
     T: int = 0
     S: int = 0
@@ -104,17 +105,18 @@ class OpsBase:
         self.gemm(GemmCall(A=x2d, W=w, out=out, M=M, N=N, K=K, bias=bias, geglu=geglu, **epi))
         return out
 
-    def conv3x3(self, x, w, bias, n_img, Hin, Win, *, stride=1, up=1, out=None, out_dtype=None, **epi):
+    def conv3x3(self, x, w, bias, n_img, Hin, Win, *, stride=1, up=1, pad_mode=0, out=None, out_dtype=None, **epi):
         """x [n_img*Hin*Win, Cin] channels-last, w [9, Cout, Cin] -> [n_img*Hout*Wout, Cout]."""
         Hl, Wl = Hin * up, Win * up
-        Hout, Wout = (Hl + 2 - 3) // stride + 1, (Wl + 2 - 3) // stride + 1
+        ptot = 1 if pad_mode else 2
+        Hout, Wout = (Hl + ptot - 3) // stride + 1, (Wl + ptot - 3) // stride + 1
         K = x.shape[-1]
         N = w.shape[-2]
         M = n_img * Hout * Wout
         if out is None:
             out = self.empty((M, N), out_dtype or self.act_dtype, x.device)
         self.gemm(GemmCall(A=x, W=w, out=out, M=M, N=N, K=K, bias=bias, mode=GEMM_CONV3X3, Hin=Hin, Win=Win,
-                           Hout=Hout, Wout=Wout, stride=stride, up=up, **epi))
+                           Hout=Hout, Wout=Wout, stride=stride, up=up, pad_mode=pad_mode, **epi))
         return out
 
     def convt3(self, x, w, bias, T, S, *, tmin=0, tmax=None, a_row0=0, M=None, out=None, out_dtype=None, **epi):

@@ -119,10 +119,26 @@ class Encoder(nn.Module):
         self.norm_out = Normalize(block_in)
         self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1, padding=1)
         self._packed = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def packed(self):
+        if self._packed is None:
+            from ....engine.packing import pack_vae_encoder
+            self._packed = pack_vae_encoder(self)
+        return self._packed
+
+    @torch.no_grad()
     def forward(self, x):
-        raise NotImplementedError("VAE Encoder execution is the next widening step (SURVEY.md §8f rank 1); "
-                                  "this build owns its parameters so checkpoints load")
+        """x [n, in_channels, H, W] -> moments [n, 2 * z_channels, H/8, W/8] fp32 (model.py:575-601) on the HIP kernels."""
+        from ....engine.vae import run_encoder
+        return run_encoder(self.packed(), x)
 
 
 class Decoder(nn.Module):

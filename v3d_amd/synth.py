@@ -115,6 +115,12 @@ def unet_config(model_channels: int = 320, attn_type: str = "softmax-xformers") 
                 merge_strategy="learned_with_images", video_kernel_size=[3, 1, 1])
 
 
+def encoder_config(ch: int = 128) -> dict:
+    """first_stage_config.encoder_config.params of V3D_512.yaml:93-110 (ch reducible for tests)."""
+    return dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=ch,
+                ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
 def decoder_config(ch: int = 128) -> dict:
     """first_stage_config.decoder_config.params of V3D_512.yaml:112-131 (ch reducible for tests)."""
     return dict(attn_type="vanilla", double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=ch,
