@@ -70,3 +70,41 @@ def test_guider_and_discretizer_api():
     uc = {k: torch.zeros_like(v) for k, v in c.items()}
     xx, ss, cc = g.prepare_inputs(x, sgm, c, uc)
     assert xx.shape[0] == 6 and ss.shape[0] == 6 and float(cc["vector"][:3].sum()) == 0.0 and float(cc["vector"][3:].sum()) == 15.0
+
+
+@pytest.mark.parametrize("ext", ["safetensors", "ckpt"])
+def test_checkpoint_round_trip_reference_format(tmp_path, ext):
+    """a reference-format checkpoint (same key names, `state_dict` wrapper for .ckpt, an unexpected key and a
+    shape-mismatched key thrown in) loads through DiffusionEngine(ckpt_path=...) exactly like video_diffusion.py:123-168 does:
+    by name, strict=False, mismatched shapes dropped - and the packed (bf16, kernel-layout) copies are rebuilt from it."""
+    cfg = configs.v3d_512_config(num_frames=3, num_steps=2, model_channels=64, vae_ch=32)
+    cfg = cfg["model"] if "model" in cfg else cfg
+    donor = instantiate_from_config(cfg).eval()
+    sd = synth.seeded_state_dict(donor, 77)
+    sd["model.diffusion_model.not_in_this_build"] = torch.zeros(3)
+    bad_key = "model.diffusion_model.out.2.bias"
+    good_shape = sd[bad_key].shape
+    sd[bad_key] = torch.zeros(good_shape[0] + 1)
+    path = str(tmp_path / f"tiny_v3d.{ext}")
+    if ext == "safetensors":
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous() for k, v in sd.items()}, path)
+    else:
+        torch.save({"state_dict": sd}, path)
+    cfg2 = configs.v3d_512_config(num_frames=3, num_steps=2, model_channels=64, vae_ch=32)
+    cfg2 = cfg2["model"] if "model" in cfg2 else cfg2
+    cfg2["params"]["ckpt_path"] = path
+    model = instantiate_from_config(cfg2).eval()
+    got = model.state_dict()
+    n_equal = sum(int(torch.equal(got[k], v)) for k, v in sd.items() if k in got and got[k].shape == v.shape)
+    assert n_equal == len(got) - 1                      # everything but the shape-mismatched bias came from the file
+    assert got[bad_key].shape == good_shape             # kept at its constructor value (zero_module)
+    # the engine runs on the loaded weights: a U-Net evaluation equals the donor's once the donor holds the same tensors
+    donor.load_state_dict({k: v for k, v in got.items()}, strict=True)
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(6, 8, 16, 16, generator=g), torch.rand(6, generator=g)
+    ctx, y = torch.randn(6, 1, 1024, generator=g), torch.randn(6, 768, generator=g)
+    with use_backend(EmulOps("cpu", exact=True)):
+        a = model.model.diffusion_model(x, t, context=ctx, y=y, num_video_frames=3, image_only_indicator=torch.zeros(2, 3))
+        b = donor.model.diffusion_model(x, t, context=ctx, y=y, num_video_frames=3, image_only_indicator=torch.zeros(2, 3))
+    assert torch.equal(a, b)
