@@ -60,11 +60,12 @@ def test_sampler_vs_reference_fixture(golden, kind, key):
     assert cos >= 0.99 and rel <= (0.2 if kind == "heun_central" else 0.1), (rel, cos)
 
 
-def test_unet_vs_oracle_other_shapes():
-    """T = 5 frames, 2 samples (cfg 2 x B 2 -> 20 images), 24 x 40 latents (non-square; tokens 960/240/60->needs %8)."""
+@pytest.mark.parametrize("T,H,W,B2", [(4, 16, 32, 4), (25, 16, 32, 2), (14, 64, 8, 2)])
+def test_unet_vs_oracle_other_shapes(T, H, W, B2):
+    """Shape variants of SURVEY 8(f)-3 at reduced width: other frame counts (SVD 14 / 25 frames), several samples per
+    batch (cfg 2 x B 2), non-square latents - against the fp32 oracle."""
     from oracle import sgm_oracle as O
     from v3d_amd import synth
-    T, H, W, B2 = 4, 16, 32, 4
     g = torch.Generator().manual_seed(123)
     n = B2 * T
     x8 = torch.randn(n, 8, H, W, generator=g)
