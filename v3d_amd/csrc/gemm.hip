@@ -5,12 +5,16 @@
 // v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand, so each lane ends up with 4 consecutive output
 // channels of one pixel (8-byte bf16 stores, float4 bias loads).
 //
-// Main loop "v2" (default): HBM/L2 -> LDS by direct LDS-DMA (global_load_lds_dwordx4, no VGPR staging) into an NS-deep
-// ring of BK=32 stages; NS-1 stages are in flight while one is consumed; counted s_waitcnt vmcnt(N) + one raw s_barrier
-// per stage (never vmcnt(0) inside the loop).  LDS rows are 64 B; the 16-byte chunk position of a row is XOR-swizzled
-// (applied on the per-lane SOURCE address, the LDS-DMA destination being lane-linear) so every ds_read_b128 lane group
-// hits 16 distinct 16-byte slots.  Conv zero padding / M,N,K tails read from a 64-byte zero page instead of branching.
-// Main loop "v1" (V3D_GEMM_IMPL=1, kept for A/B runs): register-staged double buffer with buffer loads.
+// Three main loops share the tap / row addressing (RowInfo) and the fused epilogue below:
+//   v3 (default wherever its tiles fill the CUs): persistent 8-wave blocks on 256 x 256 / 192 x 320 / 256 x 128 tiles, buffer-load
+//      LDS-DMA ring across tile boundaries, two wave groups per SIMD offset by half a step around ONE barrier per 32 k - see the
+//      block comment at gemm_kernel_v3.
+//   v2 (small-M levels, ragged edges, batched launches, split-K): one 128 x 128 / 256 x 128 / 256 x 64 tile per block, 2-3 blocks
+//      per CU; HBM/L2 -> LDS by global_load_lds_dwordx4 into an NS-deep ring of BK = 32 / 64 stages, counted s_waitcnt vmcnt(N) +
+//      one raw s_barrier per stage (never vmcnt(0) inside the loop); conv zero padding / M, N tails read a 64 KiB zero page.
+//   v1 (K % 32 != 0, V3D_GEMM_IMPL=1): register-staged double buffer with bounds-checked buffer loads.
+// LDS rows are 64 B (128 B for BK = 64); the 16-byte chunk position of a row is XOR-swizzled on the per-lane SOURCE address (the
+// LDS-DMA destination is lane-linear) so every ds_read_b128 lane group hits 16 distinct 16-byte slots.
 #include <stdlib.h>
 
 #include <type_traits>
