@@ -93,6 +93,19 @@ typedef struct v3d_gemm_args {
 } v3d_gemm_args;
 
 int v3d_gemm(const v3d_gemm_args* args, v3d_stream_t stream);
+
+/* FeedForward(GEGLU) of the transformer blocks, fused end to end (sgm/modules/attention.py:82-113: GEGLU = Linear(C, 2*hidden) ->
+ * value * gelu(gate); FeedForward = GEGLU, Dropout(0), Linear(hidden, C)); the hidden tensor never leaves the CU.
+ *   out[m][:] = ca * (W2 . geglu(W1 x[m] + b1) + b2) + c1 * res1[m] + c2 * res2[m]      (ca, c1, c2 = c_acc, c_res1, c_res2, or
+ *                                                                                         coef[(m / coef_rpg)][3] when coef != NULL)
+ * x [M][C] bf16 (row stride ldx), W1p [2*hidden][C] bf16 with value / gate rows interleaved in groups of 16 (the layout v3d_gemm's
+ * geglu flag expects), b1 packed alike; W2p [C][hidden] bf16 with the columns of every 32-channel slab permuted:
+ * W2p[o][32 s + 8 q + e] = W2[o][32 s + 16 (e >> 2) + 4 q + (e & 3)], q = 0..3, e = 0..7; b2 [C] fp32; out / res bf16.
+ * Requires C == 320 (the 64x64 level; wider levels use two v3d_gemm launches), M % 128 == 0, hidden % 32 == 0. */
+int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                 const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
+                 float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,
+                 v3d_stream_t stream);
 /* sizeof(v3d_gemm_args) as compiled into the library: lets a foreign-language binding verify its struct mirror */
 int v3d_sizeof_gemm_args(void);
 

@@ -205,6 +205,33 @@ class EmulOps(OpsBase):
         d = (x - den) / sigma.reshape(shp)
         return x + (next_sigma - sigma).reshape(shp) * d
 
+    @staticmethod
+    def ff_k_perm(hidden: int, device):
+        """Column order of W2p inside v3d_ff_fused: position 32 s + 8 q + e holds hidden channel 32 s + 16 (e >> 2) + 4 q + (e & 3)."""
+        s_, q, e = torch.meshgrid(torch.arange(hidden // 32), torch.arange(4), torch.arange(8), indexing="ij")
+        return (32 * s_ + 16 * (e >> 2) + 4 * q + (e & 3)).reshape(-1).to(device)
+
+    def ff_fused(self, x, w1p, b1, w2p, b2, out, *, res1=None, res2=None, coef=None, coef_rpg=0, c_acc=1.0, c_res1=1.0, c_res2=1.0):
+        M, Cc = x.shape
+        hidden = w2p.shape[-1]
+        sraw = x.float() @ w1p.float().t() + b1.float()                       # [M, 2*hidden], 16-interleaved value / gate
+        sg = sraw.reshape(M, hidden // 16, 2, 16)
+        h = (sg[:, :, 0] * F.gelu(sg[:, :, 1])).reshape(M, hidden)
+        h = h.to(self.act_dtype).float()                                      # the kernel feeds bf16 hidden values to the 2nd MFMA
+        y = h[:, self.ff_k_perm(hidden, x.device)] @ w2p.float().t() + b2.float()
+        if coef is not None:
+            cf = coef[(torch.arange(M, device=x.device) // coef_rpg)]
+            ca, c1, c2 = cf[:, 0:1], cf[:, 1:2], cf[:, 2:3]
+        else:
+            ca, c1, c2 = c_acc, c_res1, c_res2
+        y = ca * y
+        if res1 is not None:
+            y = y + c1 * res1.float()
+        if res2 is not None:
+            y = y + c2 * res2.float()
+        out.copy_(y.to(out.dtype))
+        return out
+
     def heun_step(self, x, den, euler, den2, sigma, next_sigma):
         shp = (x.shape[0],) + (1,) * (x.dim() - 1)
         sg, nx = sigma.reshape(shp), next_sigma.reshape(shp)

@@ -84,6 +84,30 @@ def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=Tru
     return compare(out_h, out_e)
 
 
+def case_ff_fused(hip, emu, dev, *, M, C=320, hidden=1280, res=1, coef=False, seed=0):
+    """v3d_ff_fused (GEGLU feed-forward, hidden tensor on chip) against its emulation (= two emulated GEMMs with the same packing)."""
+    g = torch.Generator().manual_seed(seed)
+    x = _rand(g, (M, C), device=dev)
+    w1 = _rand(g, (2 * hidden, C), scale=1 / math.sqrt(C), device=dev)
+    b1 = _rand(g, (2 * hidden,), F32, 0.5, dev)
+    w2 = _rand(g, (C, hidden), scale=1 / math.sqrt(hidden), device=dev)
+    b2 = _rand(g, (C,), F32, 0.5, dev)
+    kw = {}
+    if res >= 1:
+        kw.update(res1=_rand(g, (M, C), device=dev), c_res1=0.75)
+    if res >= 2:
+        kw.update(res2=_rand(g, (M, C), device=dev), c_res2=-0.5)
+    kw["c_acc"] = 0.6 if res else 1.0
+    if coef:
+        rpg = 128
+        kw.update(coef=_rand(g, ((M + rpg - 1) // rpg, 3), F32, 1.0, dev), coef_rpg=rpg)
+    o_h = torch.zeros((M, C), dtype=BF, device=dev)
+    o_e = torch.zeros((M, C), dtype=BF, device=dev)
+    hip.ff_fused(x, w1, b1, w2, b2, o_h, **kw)
+    emu.ff_fused(x, w1, b1, w2, b2, o_e, **kw)
+    return compare(o_h, o_e)
+
+
 def case_groupnorm(hip, emu, dev, *, n_img, S, C1, C2=0, imgs_per_stat=1, eps=1e-5, silu=True, seed=0):
     g = torch.Generator().manual_seed(seed)
     x1 = (_rand(g, (n_img * S, C1), F32, 1.0, dev) + 0.5).to(BF)
@@ -217,6 +241,9 @@ def all_cases(full: bool = True):
         ("gemm_geglu", case_gemm, dict(M=192, N=256, K=320, geglu=True, res=1), TOL_BF16),
         ("gemm_geglu_n64tile", case_gemm, dict(M=192, N=320, K=64, geglu=True), TOL_BF16),
         ("gemm_batched_sharedW", case_gemm, dict(M=96, N=192, K=128, batch=3, bias=False), TOL_BF16),
+        ("ff_fused_res1", case_ff_fused, dict(M=384, res=1), TOL_BF16),
+        ("ff_fused_blend", case_ff_fused, dict(M=128 * 5, res=2, coef=True), TOL_BF16),
+        ("ff_fused_plain_hidden256", case_ff_fused, dict(M=256, hidden=256, res=0), TOL_BF16),
         ("gemm_batched_perbatchW", case_gemm, dict(M=128, N=128, K=512, batch=2, bias=False, shared_w=False, out_fp32=True), TOL_BF16),
         ("conv3x3_small", case_gemm, dict(M=0, N=64, K=32, mode=C3, conv=(2, 8, 8, 1, 1)), TOL_BF16),
         ("conv3x3_odd_hw", case_gemm, dict(M=0, N=40, K=24, mode=C3, conv=(3, 7, 5, 1, 1), add=True, res=1), TOL_BF16),

@@ -106,6 +106,14 @@ class FFPack:
     b1: torch.Tensor
     w2: torch.Tensor
     b2: torch.Tensor
+    w2_fused: Optional[torch.Tensor] = None   # [C][hidden] with the per-slab K permutation of v3d_ff_fused (C = 320 only)
+
+
+def ff_fused_k_perm(hidden: int) -> torch.Tensor:
+    """Column order of W2 inside v3d_ff_fused (include/v3d_hip.h): position 32 s + 8 q + e holds hidden channel
+    32 s + 16 (e >> 2) + 4 q + (e & 3) - the order in which a lane holds its 8 GEGLU outputs after the first MFMA phase."""
+    s_, q, e = torch.meshgrid(torch.arange(hidden // 32), torch.arange(4), torch.arange(8), indexing="ij")
+    return (32 * s_ + 16 * (e >> 2) + 4 * q + (e & 3)).reshape(-1)
 
 
 @dataclass
@@ -165,7 +173,11 @@ class UNetPack:
 def _pack_ff(ff) -> FFPack:
     w1, b1 = pack_geglu(ff.net[0].proj)
     w2, b2 = pack_linear(ff.net[2])
-    return FFPack(w1, b1, w2, b2)
+    p = FFPack(w1, b1, w2, b2)
+    C, hidden = w2.shape[-2], w2.shape[-1]
+    if C == 320 and hidden % 32 == 0:
+        p.w2_fused = w2.reshape(C, hidden)[:, ff_fused_k_perm(hidden).to(w2.device)].contiguous()
+    return p
 
 
 class _Collector:

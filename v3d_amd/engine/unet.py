@@ -12,6 +12,8 @@ exist (b c h w <-> b (h w) c, (b t) s c <-> (b s) t c, th.cat of the skip, F.int
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -70,8 +72,7 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     ga, be, eps = p.s_norm3
     n3 = ops.empty((n * S, C), ops.act_dtype, x.device)
     ops.layernorm(x, ga, be, n3, eps)
-    f = ops.linear(n3, p.s_ff.w1, p.s_ff.b1, geglu=True)
-    x_s = ops.linear(f, p.s_ff.w2, p.s_ff.b2, res1=x)
+    x_s = feed_forward(ops, n3, p.s_ff, res1=x)
 
     # ---- temporal VideoTransformerBlock on x_mix = x + frame embedding (video_attention.py:109-140,286-289) ----
     frames = range(T) if sh is None else sh.local_frames
@@ -80,8 +81,7 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     x_mix = ops.empty((n * S, C), ops.act_dtype, x.device)
     nin = ops.empty((n * S, C), ops.act_dtype, x.device)
     ops.layernorm(x_s, ga, be, nin, eps, add=table, add_rpg=S, add_ld=C, xsum_out=x_mix)
-    f = ops.linear(nin, p.t_ff_in.w1, p.t_ff_in.b1, geglu=True)
-    x_t = ops.linear(f, p.t_ff_in.w2, p.t_ff_in.b2, res1=x_mix)
+    x_t = feed_forward(ops, nin, p.t_ff_in, res1=x_mix)
     ga, be, eps = p.t_norm1
     ops.layernorm(x_t, ga, be, n1, eps)
     qkv = ops.linear(n1, p.t_wqkv).view(B, T, S, 3 * C)
@@ -97,10 +97,26 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
                      add_ld=ctx_ld)
     ga, be, eps = p.t_norm3
     ops.layernorm(x_t, ga, be, n3, eps)
-    f = ops.linear(n3, p.t_ff.w1, p.t_ff.b1, geglu=True)
     # AlphaBlender fused: alpha * x_s + (1 - alpha) * (ff + x_t)
-    x = ops.linear(f, p.t_ff.w2, p.t_ff.b2, res1=x_t, res2=x_s, coef=env.coefs[p.mixer], coef_rpg=S)
+    x = feed_forward(ops, n3, p.t_ff, res1=x_t, res2=x_s, coef=env.coefs[p.mixer], coef_rpg=S)
     return ops.linear(x, p.proj_out[0], p.proj_out[1], res1=x_in)
+
+
+_FF_FUSED = os.environ.get("V3D_FF_FUSED", "1") not in ("", "0")
+
+
+def feed_forward(ops, xin, ff, *, res1, res2=None, coef=None, coef_rpg=0):
+    """FeedForward with GEGLU (attention.py:82-113): out = W2 (value * gelu(gate)) + b2 + residual(s).  At C = 320 (the 64x64 level)
+    one fused kernel keeps the 4x-wide hidden tensor on the CU (v3d_ff_fused); elsewhere two v3d_gemm launches."""
+    M, C = xin.shape
+    kw = dict(res1=res1)
+    if res2 is not None:
+        kw.update(res2=res2, coef=coef, coef_rpg=coef_rpg)
+    if _FF_FUSED and ff.w2_fused is not None and M % 128 == 0 and hasattr(ops, "ff_fused"):
+        out = ops.empty((M, C), ops.act_dtype, xin.device)
+        return ops.ff_fused(xin, ff.w1, ff.b1, ff.w2_fused, ff.b2, out, **kw)
+    f = ops.linear(xin, ff.w1, ff.b1, geglu=True)
+    return ops.linear(f, ff.w2, ff.b2, **kw)
 
 
 def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_frames, image_only_indicator, shard=None,
