@@ -98,10 +98,12 @@ int v3d_gemm(const v3d_gemm_args* args, v3d_stream_t stream);
  * value * gelu(gate); FeedForward = GEGLU, Dropout(0), Linear(hidden, C)); the hidden tensor never leaves the CU.
  *   out[m][:] = ca * (W2 . geglu(W1 x[m] + b1) + b2) + c1 * res1[m] + c2 * res2[m]      (ca, c1, c2 = c_acc, c_res1, c_res2, or
  *                                                                                         coef[(m / coef_rpg)][3] when coef != NULL)
- * x [M][C] bf16 (row stride ldx), W1p [2*hidden][C] bf16 with value / gate rows interleaved in groups of 16 (the layout v3d_gemm's
- * geglu flag expects), b1 packed alike; W2p [C][hidden] bf16 with the columns of every 32-channel slab permuted:
- * W2p[o][32 s + 8 q + e] = W2[o][32 s + 16 (e >> 2) + 4 q + (e & 3)], q = 0..3, e = 0..7; b2 [C] fp32; out / res bf16.
- * Requires C == 320 (the 64x64 level; wider levels use two v3d_gemm launches), M % 128 == 0, hidden % 32 == 0. */
+ * x [M][C] bf16 (row stride ldx); b2 [C] fp32; out / res bf16.  The weights are packed in the order the 32x32 MFMA tiles hand
+ * their rows to the lanes (v3d_amd/engine/packing.py ff_fused_pack; a, h, t in {0,1}, g in 0..3, c in 0..3, s = 32-channel slab):
+ *   W1p [2*hidden][C] bf16, b1 [2*hidden] fp32: row 64 s + 32 a + 8 g + 4 h + c = the (g odd ? gate : value) row of hidden
+ *                                               channel 32 s + 16 a + 8 (g >> 1) + 4 h + c
+ *   W2p [C][hidden] bf16:                       W2p[o][32 s + 16 a + 8 h + 4 t + c] = W2[o][32 s + 16 a + 8 t + 4 h + c]
+ * Requires C == 320 (the 64x64 level; wider levels use two v3d_gemm launches), M % 128 == 0, hidden % 64 == 0, hidden >= 128. */
 int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                  const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
                  float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,

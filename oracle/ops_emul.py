@@ -207,16 +207,17 @@ class EmulOps(OpsBase):
 
     @staticmethod
     def ff_k_perm(hidden: int, device):
-        """Column order of W2p inside v3d_ff_fused: position 32 s + 8 q + e holds hidden channel 32 s + 16 (e >> 2) + 4 q + (e & 3)."""
-        s_, q, e = torch.meshgrid(torch.arange(hidden // 32), torch.arange(4), torch.arange(8), indexing="ij")
-        return (32 * s_ + 16 * (e >> 2) + 4 * q + (e & 3)).reshape(-1).to(device)
+        """Column order of W2p inside v3d_ff_fused: position 32 s + 16 a + 8 h + 4 t + c holds hidden channel 32 s + 16 a + 8 t + 4 h + c."""
+        s_, a, h, t, c = torch.meshgrid(torch.arange(hidden // 32), torch.arange(2), torch.arange(2), torch.arange(2), torch.arange(4),
+                                        indexing="ij")
+        return (32 * s_ + 16 * a + 8 * t + 4 * h + c).reshape(-1).to(device)
 
     def ff_fused(self, x, w1p, b1, w2p, b2, out, *, res1=None, res2=None, coef=None, coef_rpg=0, c_acc=1.0, c_res1=1.0, c_res2=1.0):
         M, Cc = x.shape
         hidden = w2p.shape[-1]
-        sraw = x.float() @ w1p.float().t() + b1.float()                       # [M, 2*hidden], 16-interleaved value / gate
-        sg = sraw.reshape(M, hidden // 16, 2, 16)
-        h = (sg[:, :, 0] * F.gelu(sg[:, :, 1])).reshape(M, hidden)
+        # W1p rows: 64 s + 32 a + 8 g + 4 h + c = (g odd ? gate : value) of hidden channel 32 s + 16 a + 8 (g >> 1) + 4 h + c
+        sraw = (x.float() @ w1p.float().t() + b1.float()).reshape(M, hidden // 16, 2, 2, 8)   # [.., g >> 1, g & 1, 4 h + c]
+        h = (sraw[:, :, :, 0] * F.gelu(sraw[:, :, :, 1])).reshape(M, hidden)                   # natural channel order
         h = h.to(self.act_dtype).float()                                      # the kernel feeds bf16 hidden values to the 2nd MFMA
         y = h[:, self.ff_k_perm(hidden, x.device)] @ w2p.float().t() + b2.float()
         if coef is not None:

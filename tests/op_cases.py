@@ -244,6 +244,7 @@ def all_cases(full: bool = True):
         ("ff_fused_res1", case_ff_fused, dict(M=384, res=1), TOL_BF16),
         ("ff_fused_blend", case_ff_fused, dict(M=128 * 5, res=2, coef=True), TOL_BF16),
         ("ff_fused_plain_hidden256", case_ff_fused, dict(M=256, hidden=256, res=0), TOL_BF16),
+        ("ff_fused_two_blocks_per_cu", case_ff_fused, dict(M=128 * 300, res=1, seed=3), TOL_BF16),
         ("gemm_batched_perbatchW", case_gemm, dict(M=128, N=128, K=512, batch=2, bias=False, shared_w=False, out_fp32=True), TOL_BF16),
         ("conv3x3_small", case_gemm, dict(M=0, N=64, K=32, mode=C3, conv=(2, 8, 8, 1, 1)), TOL_BF16),
         ("conv3x3_odd_hw", case_gemm, dict(M=0, N=40, K=24, mode=C3, conv=(3, 7, 5, 1, 1), add=True, res=1), TOL_BF16),

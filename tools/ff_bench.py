@@ -27,11 +27,22 @@ print(f"two GEMMs: {ms2 * 1e3:.1f} us  ({fl / ms2 / 1e9:.0f} TF/s)")
 
 if os.environ.get("V3D_FF_TIMELINE"):
     import ctypes, numpy as np
-    buf = (ctypes.c_ulonglong * (4 * 16 * 8))()
+    buf = (ctypes.c_ulonglong * (4 * 16 * 8 + 4 * 4 * 8))()
     assert hip.lib.v3d_debug_ff_timeline(buf) == 0
-    t = (np.array(buf[:], dtype=np.uint64) & np.uint64(0x7fffffffffffffff)).astype(np.int64).reshape(4, 16, 8)
-    names = ["start", "dma_issued", "phaseA_done", "geglu_done", "phaseB_done", "vmcnt0", "barrier"]
+    t = (np.array(buf[:], dtype=np.uint64) & np.uint64(0x7fffffffffffffff)).astype(np.int64)
+    tb = t[512:].reshape(4, 4, 8)
+    t = t[:512].reshape(4, 16, 8)
+    print("tick period by stamp (wave 0):", [int(np.diff(t[0, 2:14, k]).mean()) for k in range(8)])
+    print("stamp offsets from tick start (wave 0, mean):", [int((t[0, 2:14, k] - t[0, 2:14, 0]).mean()) for k in range(8)])
+    order = [0, 4, 5, 6, 1, 2, 3]
+    names = ["start", "loads_issued", "slot19", "slot39", "slots_done", "vmcnt0", "barrier"]
     for w in range(4):
-        tt = t[w, 2:14, :7]
+        tt = t[w, 2:14][:, order]
         d = np.concatenate([np.diff(tt, axis=1)[:-1], (tt[1:, 0] - tt[:-1, 6])[:, None]], axis=1)
-        print(f"wave {w}: " + "  ".join(f"{names[i]}->{names[(i + 1) % 7]}={d[:, i].mean():.0f}" for i in range(7)) + f"  total={d.sum(1).mean():.0f}")
+        print(f"wave {w}: " + "  ".join(f"->{names[(i + 1) % 7]}={d[:, i].mean():.0f}" for i in range(7)) + f"  total={d.sum(1).mean():.0f}")
+    bn = ["block_start", "tick0_done", "steady_done", "pen_done", "boundary_done", "epilogue_done"]
+    for w in range(1):
+        for b in range(4):
+            d = np.diff(tb[w, b, :6])
+            nxt = (tb[w, b + 1, 0] - tb[w, b, 5]) if b < 3 else 0
+            print(f"wave {w} block {b}: " + "  ".join(f"{bn[i + 1]}={d[i]}" for i in range(5)) + f"  to_next={nxt}")

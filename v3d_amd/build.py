@@ -19,6 +19,9 @@ ARCH = "gfx950"
 # 537 vs 545 TF/s on the 64x64 feed-forward projection, 10.55 vs 10.67 frames/s)
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wall", "-Wno-unused-function"]
+# ff.hip lays its instruction stream out by hand in fenced issue slots; the SLP vectoriser would pair up GELU pieces that belong to
+# different slots into v_pk_*_f32 (which also cost more than they save beside MFMAs)
+FILE_FLAGS = {"ff.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -53,7 +56,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[v3d_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -4,17 +4,27 @@
 // The unfused pair (v3d_gemm with the GEGLU epilogue, then v3d_gemm) writes and re-reads a 377 MB hidden tensor per block at the
 // 64x64 level; the second GEMM streams it at ~2.9 TB/s and the first one's epilogue (one GELU per output + the stores) costs as much
 // as its main loop.  Here a block of 128 pixel rows walks the hidden dimension in slabs of 32 channels:
-//   phase A   S[64 x 32px] = W1 slab (64 packed rows = 32 value + 32 gate, 16-interleaved) . x^T      (x fragments stay in registers)
-//   GEGLU     h[32 ch] = (S_value + b) * gelu(S_gate + b)  - the lane now holds 8 hidden values of its pixel
-//   phase B   out[C x 32px] += W2[:, slab] . h               (h is the MFMA operand straight from those registers: the K order of
+//   stage A   S[64 x 32px] = W1 slab (64 packed rows: 2 fragments of 16 value + 16 gate rows) . x^T   (x fragments stay in registers)
+//   stage G   h[32 ch] = (S_value + b) * gelu(S_gate + b)  - the lane now holds 8 hidden values of its pixel per fragment
+//   stage B   out[C x 32px] += W2[:, slab] . h               (h is the MFMA operand straight from those registers: the K order of
 //                                                             W2 inside a slab is permuted at pack time to the order the lanes hold)
-// 4 waves, ONE per SIMD (512-VGPR budget: 160 output accumulators + 80 resident x fragments + 32 slab accumulators), both weight
-// streams through a double-buffered LDS slab (buffer-load LDS-DMA, one barrier per slab), LDS fragments double-buffered in registers
-// so a wave's ds_reads run under its own MFMAs.  Persistent over row blocks; the weight stream is block-independent, so the slab
-// prefetch runs across block boundaries.
+// All MFMAs are v_mfma_f32_32x32x16_bf16: with a 32-pixel wave tile every LDS fragment read (1 KiB) feeds 32 cycles of matrix work,
+// twice what 16x16x32 fragments give - the first version of this kernel was LDS-read bound in stage A.
+// 4 waves, ONE per SIMD (512-VGPR budget: 160 output accumulators + 80 resident x fragments + 2 x 32 slab accumulators).  The three
+// stages are software-pipelined across slabs: tick j runs A(j+1), G(j) and B(j-1), which are mutually independent, so the GELU VALU
+// work and the LDS-DMA issue of the next weights sit in the shadow of the MFMAs of the other two stages.  Both weight streams go
+// through double-buffered LDS slabs (buffer-load LDS-DMA, one barrier per tick); the weight stream is block-independent, so it
+// runs across row-block boundaries, where the last B of a block shares a tick with the first A of the next.
 #include <stdlib.h>
 
 #include "common.h"
+
+#ifndef FF_STAMPS
+#define FF_STAMPS 127   // which of the per-tick timeline stamps the DBG build takes (each costs a few hundred cycles)
+#endif
+#ifndef FF_ABL
+#define FF_ABL 0   // timing experiments only (tools/ff_ablate.sh): 1 no GELU, 2 no DMA, 4 no LDS fragment reads in the slots, 8 no MFMA
+#endif
 
 namespace {
 
@@ -32,234 +42,397 @@ struct FFP {
     float c_acc, c_res1, c_res2;
     int hidden;
     unsigned w1_bytes, w2_bytes;
+    int stagger_long, stagger_short, n_long;   // start delays (s_sleep units) spread over the CUs with one block more / less
 };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void ff_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ff_static_for<I + 1, N>(f);
+    }
+}
+
+// Issue order of one tick (a single scheduling region): every MFMA is followed by one LDS fragment read, its share of the GELU
+// VALU work and - every 4th - one LDS-DMA piece with its scalar address, so that a wave that is alone on its SIMD keeps the
+// matrix pipe fed while it issues everything else in the MFMA shadows (left alone the scheduler emits DMAs, MFMAs, VALU en bloc).
+template <int NMFMA, int NVALU>
+__device__ __forceinline__ void ff_tick_pipeline() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    ff_static_for<0, NMFMA>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (i % 4 == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x402, NVALU, 0);
+    });
+}
 
 __device__ __forceinline__ int ff_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // 64-byte LDS rows, see gemm.hip
 
-__device__ unsigned long long g_ff_dbg[4 * 16 * 8];   // [wave][slab 8..23][stamp] of block 0 (timeline build only)
+__device__ unsigned long long g_ff_dbg[4 * 16 * 8 + 4 * 4 * 8];   // [wave][tick 8..23][stamp] of block 0, then [wave][block 0..3][phase] (timeline build only)
 
 template <int C, bool DBG = false>
 __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
-    constexpr int NT = C / 32;                 // k steps of phase A
-    constexpr int NO = C / 16;                 // output channel fragments
+    constexpr int NT = C / 32;                 // 32-k LDS stages of a W1 slab
+    constexpr int NK = C / 16;                 // k16 steps of stage A = resident x fragments
+    constexpr int NO = C / 32;                 // 32-channel output fragments
     constexpr int W1_STAGE = 64 * 64;          // 64 packed rows x 64 B (32 k)
     constexpr int W1_BYTES = NT * W1_STAGE;
     constexpr int W2_BYTES = C * 64;           // C output rows x 64 B (the slab's 32 hidden channels)
-    constexpr int SLAB_BYTES = W1_BYTES + W2_BYTES;
-    constexpr int NP1 = NT * 4, NP2 = C / 16;
-    static_assert((NP1 + NP2) % 4 == 0 && NP1 % 4 == 0, "pieces per wave");
+    constexpr int NP1 = NT * 4, NP2 = C / 16;  // 1-KiB DMA pieces per slab
+    static_assert(NP1 % 4 == 0 && NP2 % 4 == 0, "pieces per wave");
     constexpr int PPW1 = NP1 / 4, PPW2 = NP2 / 4;
-    constexpr int HALF = NO / 2;               // output fragments per staging pass
-    constexpr int SROW = HALF * 32 + 16;
-    constexpr int STAGE_REGION = 16 * SROW;
-    static_assert(NO % 2 == 0 && (16 * HALF * 2) % 64 == 0, "staging geometry");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * SLAB_BYTES + 4 * STAGE_REGION + (DBG ? 4096 : 0)];
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lds + 2 * SLAB_BYTES + 4 * STAGE_REGION);
+    constexpr int SROW = 128 + 16;             // staged row: 64 channels + pad
+    constexpr int STAGE_REGION = 32 * SROW;
+    static_assert(NO % 2 == 0, "staging geometry");
+    constexpr int RING = 2 * W1_BYTES + 2 * W2_BYTES;
+    constexpr int B2_OFF = RING + 4 * STAGE_REGION;   // b2 lives in LDS: the epilogue's only global loads are then its prefetches
+    constexpr int DBG_OFF = B2_OFF + C * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[DBG_OFF + (DBG ? 8192 : 0)];
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lds + DBG_OFF);
     auto stamp = [&](int s_, int k) __attribute__((always_inline)) {
-        if (DBG && blockIdx.x == 0 && s_ >= 8 && s_ < 24 && (threadIdx.x & 63) == 0) dbg[((threadIdx.x >> 6) * 16 + (s_ - 8)) * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (DBG && ((FF_STAMPS >> k) & 1) && blockIdx.x == 0 && s_ >= 8 && s_ < 24 && (threadIdx.x & 63) == 0) dbg[((threadIdx.x >> 6) * 16 + (s_ - 8)) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+
+    int bcount = 0;
+    auto bstamp = [&](int k) __attribute__((always_inline)) {
+        if (DBG && blockIdx.x == 0 && bcount < 4 && (threadIdx.x & 63) == 0) dbg[512 + ((threadIdx.x >> 6) * 4 + bcount) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    unsigned char* stage = lds + 2 * SLAB_BYTES + wave * STAGE_REGION;
+    const int l31 = lane & 31, hi = lane >> 5;
+    unsigned char* const w1ring = lds;
+    unsigned char* const w2ring = lds + 2 * W1_BYTES;
+    unsigned char* stage = lds + RING + wave * STAGE_REGION;
 
     // ---- weight-slab loader: 1-KiB pieces (16 rows x 64 B), lane l -> row l >> 2, 16-byte chunk (l & 3) ^ swz(row)
     const bufrsrc_t rsW1 = make_rsrc(p.W1, p.w1_bytes);
     const bufrsrc_t rsW2 = make_rsrc(p.W2, p.w2_bytes);
     const int prow = lane >> 2;
     const unsigned kchunk_b = (unsigned)(((lane & 3) ^ ff_swz(prow)) * 16);
-    unsigned voff1[PPW1], voff2[PPW2];
-#pragma unroll
-    for (int i = 0; i < PPW1; ++i) {
-        const int q = wave + 4 * i, t = q >> 2, r4 = q & 3;
-        voff1[i] = (unsigned)(((r4 * 16 + prow) * C + t * 32) * 2) + kchunk_b;
-    }
-#pragma unroll
-    for (int i = 0; i < PPW2; ++i) {
-        const int r16 = wave + 4 * i;
-        voff2[i] = (unsigned)(((r16 * 16 + prow) * p.hidden) * 2) + kchunk_b;
-    }
+    // piece q = wave + 4 i of W1 is LDS stage i, rows 16 wave ..; of W2 rows 16 (wave + 4 i) ..: one base VGPR per stream, the rest is
+    // a scalar offset (NOT the instruction's immediate: that one is added to the LDS address as well)
+    const unsigned voff1 = (unsigned)(((wave * 16 + prow) * C) * 2) + kchunk_b;
+    const unsigned voff2 = (unsigned)(((wave * 16 + prow) * p.hidden) * 2) + kchunk_b;
+    const int w2_step = 64 * p.hidden * 2;
     const int nslab = p.hidden / 32;
-    int ld_slab = 0;
-    auto issue_slab = [&](int buf) __attribute__((always_inline)) {
-        unsigned char* sb = lds + buf * SLAB_BYTES;
-        const int so1 = ld_slab * 64 * C * 2, so2 = ld_slab * 64;
-#pragma unroll
-        for (int i = 0; i < PPW1; ++i) {
-            const int q = wave + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(sb + (q >> 2) * W1_STAGE + (q & 3) * 1024), 16,
-                                                     (int)voff1[i], so1, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < PPW2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(sb + W1_BYTES + (wave + 4 * i) * 1024), 16,
-                                                     (int)voff2[i], so2, 0, 0);
-        if (++ld_slab == nslab) ld_slab = 0;
-    };
-
-    const int frag_off = fr * 64 + ((fq ^ ff_swz(fr)) * 16);   // fragment row fr, logical chunk fq
+    int ld1 = 0, ld2 = 0;   // next slab of each weight stream (both wrap: the stream does not depend on the row block)
+    // LDS fragment of 32 rows x 16 k out of 64-byte rows: row l31, logical 16-byte chunk 2 kk + hi
+    const int foff0 = l31 * 64 + (((0 + hi) ^ ff_swz(l31)) * 16);
+    const int foff1 = l31 * 64 + (((2 + hi) ^ ff_swz(l31)) * 16);
     const long long nblocks = p.M / 128;
 
-    f32x4 acc2[2][NO];
+    f32x16 acc2[NO];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) acc2[f][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 16; ++r) acc2[o][r] = 0.f;
+    f32x16 sA[2][2];                   // slab accumulators [slab parity][row fragment]
+    bf16x8 hh[2][2];                   // GEGLU outputs      [slab parity][row fragment = k16 step of stage B]
+    bf16x8 xr[NK];                     // the wave's 32 input rows as MFMA operand fragments, resident for the whole block
 
-    issue_slab(0);
+    auto load_x = [&](long long blk) __attribute__((always_inline)) {
+        const bf16_t* xz = p.x + (blk * 128 + wave * 32 + l31) * p.ldx + hi * 8;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) xr[k] = *reinterpret_cast<const bf16x8*>(xz + k * 16);
+    };
+
+    // ---- one tick = NS issue slots, each closed by a scheduling fence: [MFMA] [LDS fragment read NPD slots ahead] [every 4th: one
+    //      LDS-DMA piece] [one third of a GELU evaluation].  A wave alone on its SIMD has nobody to cover its issue gaps, so the order
+    //      is fixed here instead of left to the scheduler (which emits the DMAs, the MFMAs and the VALU work en bloc).
+    //   stage B (parity PB): out += W2[:, slab] . h, fragment q = a NO + o                       slots 0 .. 2 NO - 1
+    //   stage A (parity PA): S = W1 slab . x^T, fragment q = 4 t + 2 kk + a                        the next 4 NT slots
+    //   stage G (parity PG): the MFMA rows of a fragment are 8 g + 4 hi + c (g = reg >> 2, c = reg & 3): g even = value, g odd =
+    //                        gate of hidden channel 8 (g >> 1) + 4 hi + c -> the lane's 8 values are one k16 operand of stage B
+    //   DMA (parity PD):     W1 slab ld1 -> w1ring[PD], W2 slab ld2 -> w2ring[PD]
+    // A parity of -1 switches the stage off.
+    auto tick = [&](auto pa_c, auto pg_c, auto pb_c, auto pd_c, int j) __attribute__((always_inline)) {
+        constexpr int PA = decltype(pa_c)::value, PG = decltype(pg_c)::value, PB = decltype(pb_c)::value, PDM = decltype(pd_c)::value;
+        constexpr int NB = PB >= 0 ? 2 * NO : 0, NA = PA >= 0 ? 4 * NT : 0, NS = 2 * NO + 4 * NT, NPD = 4;
+        stamp(j, 0);
+        // the slab accumulators start from b1 (row 8 g + 4 hi + c of fragment a <-> register 4 g + c).  Loaded before the tick's DMAs
+        // (vmcnt retires in order), moved into the accumulators in the four slots before stage A's first MFMA
+        float4 bu[4], bv[4];
+        if constexpr (PA >= 0) {
+            const float* bz = p.b1 + (j == nslab ? 0 : j + 1) * 64 + hi * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bu[g] = *reinterpret_cast<const float4*>(bz + g * 8);
+                bv[g] = *reinterpret_cast<const float4*>(bz + 32 + g * 8);
+            }
+        }
+        int so1 = 0, so2 = 0;
+        if constexpr (PDM >= 0) {
+            so1 = ld1 * 64 * C * 2;
+            so2 = ld2 * 64;
+            if (++ld1 == nslab) ld1 = 0;
+            if (++ld2 == nslab) ld2 = 0;
+        }
+        auto rd = [&](auto fc) __attribute__((always_inline)) -> bf16x8 {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f < NB)
+                return *reinterpret_cast<const bf16x8*>(w2ring + (PB < 0 ? 0 : PB) * W2_BYTES + (f % NO) * 2048 + ((f / NO) ? foff1 : foff0));
+            else {
+                constexpr int q = f - NB;
+                return *reinterpret_cast<const bf16x8*>(w1ring + (PA < 0 ? 0 : PA) * W1_BYTES + (q >> 2) * W1_STAGE + (q & 1) * 2048 +
+                                                        (((q >> 1) & 1) ? foff1 : foff0));
+            }
+        };
+        bf16x8 wf[NPD];
+        ff_static_for<0, NPD>([&](auto fc) __attribute__((always_inline)) {
+            if constexpr (decltype(fc)::value < NB + NA) wf[decltype(fc)::value] = rd(fc);
+        });
+        if constexpr (PA >= 0 && NB < 4) {   // no stage B to wait behind (first tick of a block): once per block, stall accepted
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sA[PA][0][4 * g] = bu[g].x; sA[PA][0][4 * g + 1] = bu[g].y; sA[PA][0][4 * g + 2] = bu[g].z; sA[PA][0][4 * g + 3] = bu[g].w;
+                sA[PA][1][4 * g] = bv[g].x; sA[PA][1][4 * g + 1] = bv[g].y; sA[PA][1][4 * g + 2] = bv[g].z; sA[PA][1][4 * g + 3] = bv[g].w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef FF_STAMP_B
+        stamp(j, 4);
+#endif
+        float gx = 0.f, gz = 0.f, gq = 0.f, hprev = 0.f;
+        u32x4 hw0 = {0, 0, 0, 0}, hw1 = {0, 0, 0, 0};
+        auto gstep = [&](auto ms_c) __attribute__((always_inline)) {
+            {
+                constexpr int ms = decltype(ms_c)::value, e = ms / 3, st = ms % 3;
+                if constexpr (e < 16) {
+                    constexpr int a = e / 8, idx = e % 8, vreg = idx < 4 ? idx : idx + 4, greg = vreg + 4;
+                    if constexpr (st == 0) {
+                        gx = sA[PG][a][greg];
+                        gz = fminf(fabsf(gx) * 0.70710678118654752440f, 4.0f);
+                        gq = __builtin_fmaf(-1.664338751e-02f, gz, 1.293501013e-01f);
+                        gq = __builtin_fmaf(gq, gz, 9.298687989e-01f);
+                    } else if constexpr (st == 1) {
+                        gq = __builtin_fmaf(gq, gz, 1.625731271e+00f);
+                        gq = __builtin_fmaf(gq, gz, 1.0f);
+                        gq = __builtin_amdgcn_exp2f(-gq);
+                    } else {
+                        const float hv = sA[PG][a][vreg] * (fmaxf(gx, 0.0f) - fabsf(gx) * gq);
+                        if constexpr (idx & 1) {
+                            if constexpr (a == 0) hw0[idx >> 1] = pack2bf(hprev, hv);
+                            else hw1[idx >> 1] = pack2bf(hprev, hv);
+                        } else
+                            hprev = hv;
+                    }
+                }
+            }
+        };
+        constexpr int G_FRONT = 6;
+        if constexpr (PG >= 0 && (FF_ABL & 1) == 0) {
+            ff_static_for<0, G_FRONT>([&](auto mc) __attribute__((always_inline)) { gstep(mc); });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ff_static_for<0, NS>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (PA >= 0 && NB >= 4 && i + 4 >= NB && i < NB) {
+                constexpr int g = i + 4 - NB;
+                sA[PA][0][4 * g] = bu[g].x; sA[PA][0][4 * g + 1] = bu[g].y; sA[PA][0][4 * g + 2] = bu[g].z; sA[PA][0][4 * g + 3] = bu[g].w;
+                sA[PA][1][4 * g] = bv[g].x; sA[PA][1][4 * g + 1] = bv[g].y; sA[PA][1][4 * g + 2] = bv[g].z; sA[PA][1][4 * g + 3] = bv[g].w;
+            }
+            if constexpr (i < NB + NA) {
+                const bf16x8 w = wf[i % NPD];
+                if constexpr ((FF_ABL & 8) != 0) {
+                } else if constexpr (i < NB)
+                    acc2[i % NO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, hh[PB < 0 ? 0 : PB][i / NO], acc2[i % NO], 0, 0, 0);
+                else {
+                    constexpr int q = i - NB;
+                    sA[PA < 0 ? 0 : PA][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xr[q >> 1], sA[PA < 0 ? 0 : PA][q & 1], 0, 0, 0);
+                }
+                if constexpr (i + NPD < NB + NA && (FF_ABL & 4) == 0) wf[i % NPD] = rd(std::integral_constant<int, i + NPD>{});
+            }
+            if constexpr (PDM >= 0 && i % 4 == 1 && (FF_ABL & 2) == 0) {
+                constexpr int k = i / 4;
+                if constexpr (k < PPW1)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(w1ring + PDM * W1_BYTES + k * W1_STAGE + wave * 1024),
+                                                             16, (int)voff1, so1 + k * 64, 0, 0);
+                else if constexpr (k < PPW1 + PPW2)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(w2ring + PDM * W2_BYTES + (wave + 4 * (k - PPW1)) * 1024),
+                                                             16, (int)voff2, so2 + (k - PPW1) * w2_step, 0, 0);
+            }
+            // stage G: 16 GELUs x 3 pieces over the tick's slots, plain fp32 (packed fp32 beside MFMAs costs more than it saves) and as
+            // few issue slots as the bf16 result allows - a wave alone on its SIMD hides ~5 instructions per 32x32x16 MFMA:
+            //   gelu(x) = relu(x) - |x| 2^-(z Q(z) + 1),  z = min(|x| / sqrt2, 4),  0.5 erfc(z) = 2^-(z Q(z) + 1)
+            // Q: degree-3 fit of -log2(erfc(z)) / z weighted for the GELU error (|error| <= 8.6e-6 in fp32 Horner; the value is rounded
+            // to bf16, 4e-3 relative, right after).  11 VALU + 1 transcendental per value.
+            // G_FRONT pieces run at the tick top, in the shadow of the first fragment reads' LDS latency; the rest is spread 7 per 10 slots
+            if constexpr (PG >= 0 && (FF_ABL & 1) == 0 && (i == 0 || (7 * i) / 10 != (7 * (i - 1)) / 10 || false)) {
+                constexpr int ms = G_FRONT + (i == 0 ? 0 : (7 * i) / 10);
+                if constexpr (ms < 48) gstep(std::integral_constant<int, ms>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef FF_STAMP_B
+            if constexpr (i >= FF_STAMP_B && i < FF_STAMP_B + 7) stamp(j, 1 + i - FF_STAMP_B);
+#else
+            if constexpr (i == 19) stamp(j, 5);
+            if constexpr (i == 39) stamp(j, 6);
+#endif
+        });
+        if constexpr (PG >= 0) {
+            hh[PG][0] = __builtin_bit_cast(bf16x8, hw0);
+            hh[PG][1] = __builtin_bit_cast(bf16x8, hw1);
+        }
+#ifndef FF_STAMP_B
+        stamp(j, 1);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next weights (and x) has landed
+#ifndef FF_STAMP_B
+        stamp(j, 2);
+#endif
+        __builtin_amdgcn_s_barrier();                      // ... everyone's has, and every LDS read of this tick was consumed
+#ifndef FF_STAMP_B
+        stamp(j, 3);
+#endif
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IX = std::integral_constant<int, -1>;
+
+    // ---- prologue: W1(0), W1(1) in flight (as the two ticks before a block would have left them), first x block, A(0) alone
+    long long blk = blockIdx.x;
+    if (tid < C / 4) reinterpret_cast<float4*>(lds + B2_OFF)[tid] = reinterpret_cast<const float4*>(p.b2)[tid];
+    {   // All CUs run identical blocks, so without this they stay in lockstep and their epilogues (and x fetches) hit HBM as one
+        // burst of grid x 240 KB while the memory system idles during the ticks.  The CUs that get one block less have a whole block
+        // time of slack; the others are spread over a quarter of it.
+        const int c = (int)blockIdx.x;
+        const int n = c < p.n_long ? (p.n_long > 1 ? c * p.stagger_long / p.n_long : 0)
+                                   : ((int)gridDim.x > p.n_long ? (c - p.n_long) * p.stagger_short / ((int)gridDim.x - p.n_long) : 0);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+    ff_static_for<0, 2 * PPW1>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int k = decltype(ic)::value % PPW1, par = decltype(ic)::value / PPW1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(w1ring + par * W1_BYTES + k * W1_STAGE + wave * 1024), 16,
+                                                 (int)voff1, par * 64 * C * 2 + k * 64, 0, 0);
+    });
+    ld1 = 2;
+    load_x(blk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int buf = 0;
+    tick(I0{}, IX{}, IX{}, IX{}, -1);
 
-    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const long long mw0 = blk * 128 + wave * 32;
-        // the wave's 32 input rows as MFMA operand fragments, resident for the whole block
-        bf16x8 xr[2][NT];
+    // residual rows of one epilogue pass (64 channels): res1 coalesced (row c >> 3, 16-byte chunk c & 7), res2 in the MFMA layout
+    u32x4 r1[2][4];
+    u32x2 r2[2][8];
+    auto fetch_res = [&](long long mw0_, int ps, u32x4 (&q1)[4], u32x2 (&q2)[8]) __attribute__((always_inline)) {
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));   // keep the address arithmetic out of the block loop's live ranges (see the epilogue)
+        if (p.res1) {
+            const bf16_t* rz = p.res1 + mw0_ * p.ldr1 + ps * 64;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                xr[f][t] = *reinterpret_cast<const bf16x8*>(p.x + (mw0 + f * 16 + fr) * p.ldx + t * 32 + fq * 8);
-
-        for (int s = 0; s < nslab; ++s) {
-            stamp(s, 0);
-            // bias first: vmcnt retires in order, a bias load issued behind the 15 slab DMAs would make the GEGLU wait for all of them
-            float4 bv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(p.b1 + s * 64 + j * 16 + fq * 4);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_slab(buf ^ 1);   // the other buffer was released by the barrier that ended the previous slab
-            const unsigned char* sb = lds + buf * SLAB_BYTES;
-            stamp(s, 1);
-
-            // ---- phase A: S = W1 slab . x^T, fragments of step t+1 read while step t's MFMAs run
-            f32x4 acc1[2][4];
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc1[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // W1 fragments run PD steps ahead of their MFMAs in a register ring (one wave per SIMD: nothing else hides the LDS latency)
-            constexpr int PD = 2;
-            bf16x8 wf[PD + 1][4];
-#pragma unroll
-            for (int t0 = 0; t0 < PD; ++t0)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[t0][j] = *reinterpret_cast<const bf16x8*>(sb + t0 * W1_STAGE + frag_off + j * 1024);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t + PD < NT) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        wf[(t + PD) % (PD + 1)][j] = *reinterpret_cast<const bf16x8*>(sb + (t + PD) * W1_STAGE + frag_off + j * 1024);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        acc1[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t % (PD + 1)][j], xr[f][t], acc1[f][j], 0, 0, 0);
+            for (int it = 0; it < 4; ++it) {
+                const int c = it * 64 + lane_e;
+                q1[it] = *reinterpret_cast<const u32x4*>(rz + (long long)(c >> 3) * p.ldr1 + (c & 7) * 8);
             }
-            stamp(s, 2);
-            // first W2 fragments on their way while the GELUs run
-            constexpr int G = 5;   // W2 fragments per register batch
-            static_assert(NO % G == 0, "phase B batching");
-            bf16x8 w2[2][G];
+        } else {
 #pragma unroll
-            for (int g = 0; g < G; ++g) w2[0][g] = *reinterpret_cast<const bf16x8*>(sb + W1_BYTES + frag_off + g * 1024);
-
-            // ---- GEGLU: fragments (0,1) = value / gate of hidden channels 0..15 of the slab, (2,3) = 16..31; a lane owns channels
-            //      4 fq .. 4 fq + 3 of each -> 8 hidden values of pixel fr = one k-slice of phase B in the packed K order
-            bf16x8 hB[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                float h[8];
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const float4 bvv = bv[2 * pr], bgg = bv[2 * pr + 1];
-                    const float vb[4] = {bvv.x, bvv.y, bvv.z, bvv.w}, gb[4] = {bgg.x, bgg.y, bgg.z, bgg.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h[pr * 4 + r] = (acc1[f][2 * pr][r] + vb[r]) * gelu_erf_tight(acc1[f][2 * pr + 1][r] + gb[r]);
-                }
-                const u32x4 u = {pack2bf(h[0], h[1]), pack2bf(h[2], h[3]), pack2bf(h[4], h[5]), pack2bf(h[6], h[7])};
-                hB[f] = __builtin_bit_cast(bf16x8, u);
-            }
-
-            stamp(s, 3);
-            // ---- phase B: out += W2[:, slab] . h
-#pragma unroll
-            for (int ob = 0; ob < NO / G; ++ob) {
-                if (ob + 1 < NO / G) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        w2[(ob + 1) & 1][g] = *reinterpret_cast<const bf16x8*>(sb + W1_BYTES + frag_off + ((ob + 1) * G + g) * 1024);
-                }
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        acc2[f][ob * G + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[ob & 1][g], hB[f], acc2[f][ob * G + g], 0, 0, 0);
-            }
-            stamp(s, 4);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next slab has landed (and every LDS read of this one was consumed)
-            stamp(s, 5);
-            __builtin_amdgcn_s_barrier();
-            stamp(s, 6);
-            buf ^= 1;
+            for (int it = 0; it < 4; ++it) q1[it] = u32x4{0, 0, 0, 0};
         }
-
-        // ---- block epilogue: out = c_acc (acc + b2) + c1 res1 + c2 res2, 16 rows x C/2 channels per staging pass
+        if (p.res2) {
+            const bf16_t* rz = p.res2 + (mw0_ + (lane_e & 31)) * p.ldr2 + ps * 64 + (lane_e >> 5) * 4;
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const long long m = mw0 + f * 16 + fr;
+            for (int k = 0; k < 8; ++k) q2[k] = *reinterpret_cast<const u32x2*>(rz + (k >> 2) * 32 + (k & 3) * 8);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q2[k] = u32x2{0, 0};
+        }
+    };
+
+    while (true) {
+        const long long mw0 = blk * 128 + wave * 32;
+        bstamp(0);
+        tick(I1{}, I0{}, IX{}, I0{}, 0);                   // A(1) G(0)
+        bstamp(1);
+        for (int j = 1; j + 2 < nslab; j += 2) {
+            tick(I0{}, I1{}, I0{}, I1{}, j);               // A(j+1) G(j) B(j-1)
+            tick(I1{}, I0{}, I1{}, I0{}, j + 1);
+        }
+        // penultimate tick: no A (its x fragments are dead: fetch the next block's), then the boundary tick A'(0) + B(last)
+        const long long nxt = blk + gridDim.x;
+        bstamp(2);
+        load_x(nxt < nblocks ? nxt : blk);
+        tick(IX{}, I1{}, I0{}, I1{}, nslab - 1);           // G(last) B(last-1)
+        bstamp(3);
+        fetch_res(mw0, 0, r1[0], r2[0]);                   // the epilogue's first pass: in flight under the boundary tick
+        tick(I0{}, IX{}, I1{}, IX{}, nslab);               // A'(0) B(last)
+        bstamp(4);
+
+        // ---- block epilogue: out = c_acc (acc + b2) + c1 res1 + c2 res2, 32 rows x 64 channels per staging pass
+        {
+            // the lane ids go through an opaque copy: otherwise every address below is hoisted out of the block loop, ~80 VGPRs that
+            // live (spilled) through the ticks and make the scheduler refuse the interleaved tick order as too register-hungry
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int l31 = lane_e & 31, hi = lane_e >> 5, lane = lane_e;
+            const long long m = mw0 + l31;
             float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
             if (p.coef) {
                 const float* cf = p.coef + (m / p.coef_rpg) * 3;
                 ca = cf[0]; c1 = cf[1]; c2 = cf[2];
             }
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                constexpr int CPRO = HALF * 2;                 // 16-byte chunks per staged row
-                const int col0 = hf * HALF * 16;
+            for (int ps = 0; ps < NO / 2; ++ps) {
+                const int col0 = ps * 64;
+                if (ps + 1 < NO / 2) fetch_res(mw0, ps + 1, r1[(ps + 1) & 1], r2[(ps + 1) & 1]);   // one pass ahead of its use
                 if (p.res1) {                                  // coalesced residual rows -> LDS -> MFMA layout
-                    const bf16_t* rz = p.res1 + (mw0 + f * 16) * p.ldr1 + col0;
 #pragma unroll
-                    for (int c0 = 0; c0 < 16 * CPRO; c0 += 64) {
-                        const int c = c0 + lane;
-                        *reinterpret_cast<uint4*>(stage + (c / CPRO) * SROW + (c % CPRO) * 16) =
-                            *reinterpret_cast<const uint4*>(rz + (long long)(c / CPRO) * p.ldr1 + (c % CPRO) * 8);
+                    for (int it = 0; it < 4; ++it) {
+                        const int c = it * 64 + lane;
+                        *reinterpret_cast<u32x4*>(stage + (c >> 3) * SROW + (c & 7) * 16) = r1[ps & 1][it];
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
 #pragma unroll
-                for (int oo = 0; oo < HALF; ++oo) {
-                    const int o = hf * HALF + oo;
-                    const float4 b = *reinterpret_cast<const float4*>(p.b2 + o * 16 + fq * 4);
-                    float v[4] = {ca * (acc2[f][o][0] + b.x), ca * (acc2[f][o][1] + b.y), ca * (acc2[f][o][2] + b.z), ca * (acc2[f][o][3] + b.w)};
-                    if (p.res1) {
-                        const uint2 rr = *reinterpret_cast<const uint2*>(stage + fr * SROW + oo * 32 + fq * 8);
-                        v[0] += c1 * bflo(rr.x); v[1] += c1 * bfhi(rr.x); v[2] += c1 * bflo(rr.y); v[3] += c1 * bfhi(rr.y);
+                for (int oo = 0; oo < 2; ++oo) {
+                    const int o = ps * 2 + oo;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = oo * 32 + g * 8 + hi * 4;          // channel inside the pass
+                        const float4 b = *reinterpret_cast<const float4*>(lds + B2_OFF + (col0 + ch) * 4);
+                        float v[4] = {ca * (acc2[o][4 * g + 0] + b.x), ca * (acc2[o][4 * g + 1] + b.y), ca * (acc2[o][4 * g + 2] + b.z),
+                                      ca * (acc2[o][4 * g + 3] + b.w)};
+                        if (p.res1) {
+                            const uint2 rr = *reinterpret_cast<const uint2*>(stage + l31 * SROW + ch * 2);
+                            v[0] += c1 * bflo(rr.x); v[1] += c1 * bfhi(rr.x); v[2] += c1 * bflo(rr.y); v[3] += c1 * bfhi(rr.y);
+                        }
+                        if (p.res2) {
+                            const u32x2 rr = r2[ps & 1][oo * 4 + g];
+                            v[0] += c2 * bflo(rr.x); v[1] += c2 * bfhi(rr.x); v[2] += c2 * bflo(rr.y); v[3] += c2 * bfhi(rr.y);
+                        }
+                        *reinterpret_cast<uint2*>(stage + l31 * SROW + ch * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     }
-                    if (p.res2) {
-                        const uint2 rr = *reinterpret_cast<const uint2*>(p.res2 + m * p.ldr2 + o * 16 + fq * 4);
-                        v[0] += c2 * bflo(rr.x); v[1] += c2 * bfhi(rr.x); v[2] += c2 * bflo(rr.y); v[3] += c2 * bfhi(rr.y);
-                    }
-                    *reinterpret_cast<uint2*>(stage + fr * SROW + oo * 32 + fq * 8) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                    acc2[f][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[o][r] = 0.f;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                bf16_t* oz = p.out + (mw0 + f * 16) * p.ldo + col0;
+                bf16_t* oz = p.out + mw0 * p.ldo + col0;
 #pragma unroll
-                for (int c0 = 0; c0 < 16 * CPRO; c0 += 64) {
+                for (int c0 = 0; c0 < 256; c0 += 64) {
                     const int c = c0 + lane;
-                    *reinterpret_cast<uint4*>(oz + (long long)(c / CPRO) * p.ldo + (c % CPRO) * 8) =
-                        *reinterpret_cast<const uint4*>(stage + (c / CPRO) * SROW + (c % CPRO) * 16);
+                    *reinterpret_cast<uint4*>(oz + (long long)(c >> 3) * p.ldo + (c & 7) * 8) =
+                        *reinterpret_cast<const uint4*>(stage + (c >> 3) * SROW + (c & 7) * 16);
                 }
             }
         }
+        bstamp(5);
+        ++bcount;
+        if (nxt >= nblocks) break;
+        blk = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (DBG && blockIdx.x == 0 && (threadIdx.x & 63) < 16)
         for (int k = 0; k < 8; ++k) g_ff_dbg[((threadIdx.x >> 6) * 16 + (threadIdx.x & 63)) * 8 + k] = dbg[((threadIdx.x >> 6) * 16 + (threadIdx.x & 63)) * 8 + k];
+    if (DBG && blockIdx.x == 0 && (threadIdx.x & 63) < 4)
+        for (int k = 0; k < 8; ++k) {
+            const int o = 512 + ((threadIdx.x >> 6) * 4 + (threadIdx.x & 63)) * 8 + k;
+            g_ff_dbg[o] = dbg[o];
+        }
 }
 
 }  // namespace
@@ -274,7 +447,7 @@ extern "C" int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const f
                             v3d_stream_t stream) {
     V3D_REQUIRE(x && W1p && b1 && W2p && b2 && out, "v3d_ff_fused: null pointer");
     V3D_REQUIRE(C == 320, "v3d_ff_fused: built for C = 320 (got %d); wider levels use the two-GEMM path", C);
-    V3D_REQUIRE(hidden > 0 && hidden % 32 == 0 && hidden * (long long)C * 4 < (1ll << 31), "v3d_ff_fused: bad hidden size %d", hidden);
+    V3D_REQUIRE(hidden >= 128 && hidden % 64 == 0 && hidden * (long long)C * 4 < (1ll << 31), "v3d_ff_fused: bad hidden size %d", hidden);
     V3D_REQUIRE(M > 0 && M % 128 == 0, "v3d_ff_fused: M must be a multiple of 128 (got %lld)", (long long)M);
     V3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && (!res1 || ldr1 % 8 == 0) && (!res2 || ldr2 % 4 == 0), "v3d_ff_fused: row strides");
     V3D_REQUIRE(((((uintptr_t)x | (uintptr_t)W1p | (uintptr_t)W2p | (uintptr_t)out | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0) &&
@@ -290,10 +463,19 @@ extern "C" int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const f
     p.w2_bytes = (unsigned)((long long)C * hidden * 2);
     const long long nblocks = M / 128;
     const int grid = (int)(nblocks < v3d_num_cus() ? nblocks : v3d_num_cus());
-    static int dbg = -1;
+    static int dbg = -1, stagger = 36;   // stagger: one block time in s_sleep(64) units (~4096 cycles each); V3D_FF_STAGGER=0 disables
     if (dbg < 0) {
         const char* e = getenv("V3D_FF_TIMELINE");
         dbg = e ? atoi(e) : 0;
+        if (const char* s2 = getenv("V3D_FF_STAGGER")) stagger = atoi(s2);
+    }
+    p.n_long = 0; p.stagger_long = 0; p.stagger_short = 0;
+    if (nblocks > grid && stagger > 0) {
+        const int rem = (int)(nblocks % grid);
+        p.n_long = rem ? rem : grid;
+        p.stagger_long = stagger / 4;
+        p.stagger_short = rem ? stagger * hidden / 1280 : 0;
+        p.stagger_long = p.stagger_long * hidden / 1280;
     }
     if (dbg)
         hipLaunchKernelGGL((ff_fused_kernel<320, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);

@@ -106,14 +106,34 @@ class FFPack:
     b1: torch.Tensor
     w2: torch.Tensor
     b2: torch.Tensor
-    w2_fused: Optional[torch.Tensor] = None   # [C][hidden] with the per-slab K permutation of v3d_ff_fused (C = 320 only)
+    # v3d_ff_fused operands (C = 320 only), see ff_fused_pack
+    w1_fused: Optional[torch.Tensor] = None
+    b1_fused: Optional[torch.Tensor] = None
+    w2_fused: Optional[torch.Tensor] = None
+
+
+def ff_fused_row_order(hidden: int) -> torch.Tensor:
+    """Row order of W1p / b1 inside v3d_ff_fused (include/v3d_hip.h), as indices into the Linear's [value rows ; gate rows]:
+    row 64 s + 32 a + 8 g + 4 h + c holds the (g odd ? gate : value) row of hidden channel 32 s + 16 a + 8 (g >> 1) + 4 h + c -
+    the order in which the rows of a 32x32 MFMA tile land in a lane's accumulator registers."""
+    s_, a, g, h, c = torch.meshgrid(torch.arange(hidden // 32), torch.arange(2), torch.arange(4), torch.arange(2), torch.arange(4),
+                                    indexing="ij")
+    return ((g & 1) * hidden + 32 * s_ + 16 * a + 8 * (g >> 1) + 4 * h + c).reshape(-1)
 
 
 def ff_fused_k_perm(hidden: int) -> torch.Tensor:
-    """Column order of W2 inside v3d_ff_fused (include/v3d_hip.h): position 32 s + 8 q + e holds hidden channel
-    32 s + 16 (e >> 2) + 4 q + (e & 3) - the order in which a lane holds its 8 GEGLU outputs after the first MFMA phase."""
-    s_, q, e = torch.meshgrid(torch.arange(hidden // 32), torch.arange(4), torch.arange(8), indexing="ij")
-    return (32 * s_ + 16 * (e >> 2) + 4 * q + (e & 3)).reshape(-1)
+    """Column order of W2p inside v3d_ff_fused: position 32 s + 16 a + 8 h + 4 t + c holds hidden channel 32 s + 16 a + 8 t + 4 h + c
+    - the order in which a lane holds its 8 GEGLU outputs after the first MFMA stage."""
+    s_, a, h, t, c = torch.meshgrid(torch.arange(hidden // 32), torch.arange(2), torch.arange(2), torch.arange(2), torch.arange(4),
+                                    indexing="ij")
+    return (32 * s_ + 16 * a + 8 * t + 4 * h + c).reshape(-1)
+
+
+def ff_fused_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
+    """Linear(C, 2 hidden).weight / .bias and Linear(hidden, C).weight -> (W1p, b1p, W2p) of v3d_ff_fused."""
+    hidden = w2.shape[-1]
+    ro = ff_fused_row_order(hidden).to(w1.device)
+    return _bf(w1[ro]), _f(b1[ro]), _bf(w2.reshape(-1, hidden)[:, ff_fused_k_perm(hidden).to(w2.device)])
 
 
 @dataclass
@@ -175,8 +195,9 @@ def _pack_ff(ff) -> FFPack:
     w2, b2 = pack_linear(ff.net[2])
     p = FFPack(w1, b1, w2, b2)
     C, hidden = w2.shape[-2], w2.shape[-1]
-    if C == 320 and hidden % 32 == 0:
-        p.w2_fused = w2.reshape(C, hidden)[:, ff_fused_k_perm(hidden).to(w2.device)].contiguous()
+    if C == 320 and hidden % 64 == 0 and hidden >= 128:
+        lin1, lin2 = ff.net[0].proj, ff.net[2]
+        p.w1_fused, p.b1_fused, p.w2_fused = ff_fused_pack(lin1.weight.detach(), lin1.bias.detach(), lin2.weight.detach())
     return p
 
 

@@ -114,7 +114,7 @@ def feed_forward(ops, xin, ff, *, res1, res2=None, coef=None, coef_rpg=0):
         kw.update(res2=res2, coef=coef, coef_rpg=coef_rpg)
     if _FF_FUSED and ff.w2_fused is not None and M % 128 == 0 and hasattr(ops, "ff_fused"):
         out = ops.empty((M, C), ops.act_dtype, xin.device)
-        return ops.ff_fused(xin, ff.w1, ff.b1, ff.w2_fused, ff.b2, out, **kw)
+        return ops.ff_fused(xin, ff.w1_fused, ff.b1_fused, ff.w2_fused, ff.b2, out, **kw)
     f = ops.linear(xin, ff.w1, ff.b1, geglu=True)
     return ops.linear(f, ff.w2, ff.b2, **kw)
 
