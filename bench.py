@@ -84,7 +84,7 @@ def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False
 
 
 def measure_gemm_roofline(step):
-    """One extra instrumented sample: HIP events around every v3d_gemm launch on the launch stream."""
+    """One extra instrumented sample: HIP events around every v3d_gemm / v3d_ff_fused launch on the launch stream."""
     from v3d_amd.ops import get_ops
     ops = get_ops()
     orig = ops.gemm
@@ -102,12 +102,28 @@ def measure_gemm_roofline(step):
         by += sum(g.M * nout * 2 for r in (g.res1, g.res2) if r is not None)
         rec.append((e0, e1, 2.0 * g.M * g.N * g.K * taps * g.batch, by))
 
+    orig_ff = ops.ff_fused
+
+    def timed_ff(x, w1p, b1, w2p, b2, out, **kw):
+        # the fused feed-forward is both GEMMs of the block in one launch: 2 M C (2 hidden) + 2 M hidden C flops; algorithmic bytes =
+        # x, both weight matrices, the output and the residuals once (the hidden tensor never exists in memory)
+        M, C, hidden = x.shape[0], x.shape[1], w2p.shape[-1]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_ff(x, w1p, b1, w2p, b2, out, **kw)
+        e1.record()
+        by = 2 * M * C * 2 + 3 * C * hidden * 2 + sum(M * C * 2 for k in ("res1", "res2") if kw.get(k) is not None)
+        rec.append((e0, e1, 6.0 * M * C * hidden, by))
+        return r
+
     ops.gemm = timed
+    ops.ff_fused = timed_ff
     try:
         step()
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
+        ops.ff_fused = orig_ff
     tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
     flops = sum(f for _, _, f, _ in rec)
     alg_bytes = sum(b for _, _, _, b in rec)
@@ -117,14 +133,14 @@ def measure_gemm_roofline(step):
     # separate runs, calibrated on a copy of known size as MI355X_MICROARCH.md prescribes; tools/pmc_eval.py + pmc_traffic.py)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01k_pmc_traffic.json")))
         fams = [v for k, v in pmc["families"].items() if k.startswith("gemm_")]
         traffic = round(sum(v["read_GB_per_eval"] + v["write_GB_per_eval"] for v in fams) * 1e9 / sum(v["launches_per_eval"] for v in fams))
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3<192x320 | 256x256> + gemm_kernel_v2<128x128 ...> (conv3x3 / convt3 / linear / GEGLU)",
+    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3<192x320 | 256x256> + gemm_kernel_v2<128x128 ...> (conv3x3 / convt3 / linear / GEGLU) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC, profiles/r01j_pmc_traffic.txt)",
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC, profiles/r01k_pmc_traffic.txt)",
             "algorithmic_bytes_per_launch": round(alg_bytes / n), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / n, 2),
             "algorithmic_tflop_per_sample": round(flops / 1e12, 2), "gemm_ms_per_sample": round(tot_ms, 2),
             "measured_on": "one extra instrumented sample after the timed region (HIP events per launch)"}

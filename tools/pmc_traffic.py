@@ -26,7 +26,7 @@ def per_kernel(path, counter):
 
 
 def family(name):
-    for key, fam in (("gemm_kernel_v3", "gemm_v3"), ("gemm_kernel_v2", "gemm_v2"), ("gemm_kernel_v1", "gemm_v1"), ("attn_spatial", "attn_spatial"),
+    for key, fam in (("ff_fused_kernel", "gemm_ff_fused"), ("gemm_kernel_v3", "gemm_v3"), ("gemm_kernel_v2", "gemm_v2"), ("gemm_kernel_v1", "gemm_v1"), ("attn_spatial", "attn_spatial"),
                      ("attn_temporal", "attn_temporal"), ("gn_stats", "gn_stats"), ("gn_apply", "gn_apply"), ("layernorm", "layernorm"),
                      ("copy2d", "copy2d(calibration)")):
         if key in name:

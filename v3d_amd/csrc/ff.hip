@@ -463,7 +463,8 @@ extern "C" int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const f
     p.w2_bytes = (unsigned)((long long)C * hidden * 2);
     const long long nblocks = M / 128;
     const int grid = (int)(nblocks < v3d_num_cus() ? nblocks : v3d_num_cus());
-    static int dbg = -1, stagger = 36;   // stagger: one block time in s_sleep(64) units (~4096 cycles each); V3D_FF_STAGGER=0 disables
+    static int dbg = -1, stagger = 0;   // V3D_FF_STAGGER: one block time in s_sleep(64) units (~4096 cycles each), e.g. 36; off by
+                                        // default (measured neutral once the epilogue prefetched its residuals: 494.5 vs 493.7 us)
     if (dbg < 0) {
         const char* e = getenv("V3D_FF_TIMELINE");
         dbg = e ? atoi(e) : 0;
