@@ -187,6 +187,15 @@ int v3d_euler_step(const float* x, const float* den, const float* sigma, const f
  * d = (x - den)/sigma[n]; d_new = (euler - den2)/next[n]; out = next[n] > 0 ? x + (next[n]-sigma[n]) * (d + d_new)/2 : euler */
 int v3d_heun_step(const float* x, const float* den, const float* euler, const float* den2, const float* sigma,
                   const float* next_sigma, float* out, int64_t n, int64_t chw, v3d_stream_t stream);
+/* CLIP image front-end: FrozenOpenCLIPImageEmbedder.preprocess (sgm/modules/encoders/modules.py:645-657 =
+ * kornia.geometry.resize(x, (S,S), "bicubic", align_corners=True, antialias): Gaussian blur (sigma = max((in/out - 1)/2, .001), kernel
+ * int(max(4 sigma, 3)) made odd, reflect border) when down-scaling, then bicubic A = -0.75; (x+1)/2; (x - mean)/std) fused with the patch
+ * unfold of open_clip VisionTransformer.conv1 (kernel = stride = P): img [B][3][H][W] fp32 in [-1,1] -> patches [B*(S/P)^2][Kpad] bf16,
+ * column c*P*P + ky*P + kx (= conv1.weight.reshape(width, 3*P*P) order), columns >= 3*P*P zero. mean3 / std3 are HOST pointers. */
+int v3d_clip_preprocess(const float* img, int64_t B, int32_t H, int32_t W, int32_t S, int32_t P, int32_t antialias,
+                        const float* mean3, const float* std3, void* patches_bf16, int32_t Kpad, v3d_stream_t stream);
+/* out = gelu(in), exact-erf form (nn.GELU in open_clip's ViT MLP), bf16, n % 8 == 0 */
+int v3d_gelu_bf16(const void* in, void* out, int64_t n, v3d_stream_t stream);
 /* x[n][...] *= s  (sampling.py:50) ; generic y = a*x + b on fp32 */
 int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream);
 /* AlphaBlender coefficients (diffusionmodules/util.py:341-369): for mixer i with alpha_i = sigmoid(mix_factor_i)

@@ -66,9 +66,9 @@ class EmulOps(OpsBase):
 
     def gemm(self, g: GemmCall):
         for z in range(g.batch):
-            A = g.A[z] if (g.batch > 1 and g.A.dim() == 3) else g.A
-            W = g.W[z] if (g.batch > 1 and g.W.dim() == 3 and g.mode == GEMM_LINEAR) else g.W
-            out = g.out[z] if (g.batch > 1) else g.out
+            A = g.A[z] if (g.A.dim() == 3 and g.mode == GEMM_LINEAR and (g.batch > 1 or g.out.dim() == 3)) else g.A
+            W = g.W[z] if (g.W.dim() == 3 and g.mode == GEMM_LINEAR and (g.batch > 1 or g.out.dim() == 3)) else g.W
+            out = g.out[z] if (g.batch > 1 or g.out.dim() == 3) else g.out
             M, N = g.M, g.N
             v = self._gemm_acc(g, A, W)
             if g.bias is not None:
@@ -232,6 +232,40 @@ class EmulOps(OpsBase):
             y = y + c2 * res2.float()
         out.copy_(y.to(out.dtype))
         return out
+
+    def clip_preprocess(self, img, size, patch, antialias, mean, std, kpad):
+        """kornia.geometry.resize(bicubic, align_corners=True, antialias) restated with torch ops + normalise + patch unfold."""
+        B, _, H, W = img.shape
+        x = img.float()
+        fy, fx = H / size, W / size
+        if antialias and max(fy, fx) > 1:
+            sg = (max((fy - 1.0) / 2.0, 0.001), max((fx - 1.0) / 2.0, 0.001))
+            ks = [int(max(4.0 * s_, 3)) for s_ in sg]
+            ks = [k + 1 if k % 2 == 0 else k for k in ks]
+
+            def g1(k, s_):
+                t = torch.arange(k, dtype=torch.float32, device=x.device) - k // 2
+                w = torch.exp(-t * t / (2.0 * s_ * s_))
+                return w / w.sum()
+            ky, kx = g1(ks[0], sg[0]), g1(ks[1], sg[1])
+            xp = F.pad(x, (ks[1] // 2, ks[1] // 2, ks[0] // 2, ks[0] // 2), mode="reflect")
+            w2 = (ky[:, None] * kx[None, :])[None, None].repeat(3, 1, 1, 1)
+            x = F.conv2d(xp, w2, groups=3)
+        x = F.interpolate(x, size=(size, size), mode="bicubic", align_corners=True)
+        x = (x + 1.0) / 2.0
+        x = (x - torch.tensor(mean, device=x.device).view(1, 3, 1, 1)) / torch.tensor(std, device=x.device).view(1, 3, 1, 1)
+        g = size // patch
+        pt = x.reshape(B, 3, g, patch, g, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, 3 * patch * patch)
+        out = torch.zeros(B * g * g, kpad, dtype=self.act_dtype, device=img.device)
+        out[:, :3 * patch * patch] = pt.to(self.act_dtype)
+        return out
+
+    def gelu(self, x, out=None):
+        y = F.gelu(x.float()).to(x.dtype)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     def heun_step(self, x, den, euler, den2, sigma, next_sigma):
         shp = (x.shape[0],) + (1,) * (x.dim() - 1)

@@ -5,10 +5,11 @@ scripts/pub/V3D_512.py: same `sample_one` keyword arguments, same order of opera
     python scripts/pub/V3D_512.py --input_path assets/img.png --checkpoint_path ckpts/V3D_512.ckpt ...
     python scripts/pub/V3D_512.py --synthetic                 # random-init weights + synthetic conditioning (no checkpoints)
 
-The hot path (sampler loop over VideoUNet + VideoDecoder decode) runs on the hand-written gfx950 kernels.  The image
-front-end of the reference (rembg matting, kiui recentering, OpenCLIP image embedding, VAE encode) is outside this
-build's scope: with real inputs the caller supplies `cond_frames` / `cond_frames_without_noise`
-tensors (e.g. computed with the reference's own front-end); `--synthetic` fabricates them with the right shapes.
+The hot path (sampler loop over VideoUNet + VideoDecoder decode) runs on the hand-written gfx950 kernels, and so does the
+conditioning front-end of SURVEY.md §8f rank 1: the OpenCLIP ViT-H/14 image embedding (`clip_model(image)`, V3D_512.py:146-153,
+238) and the VAE encode (`ae_model.encode(image)`, :239) of the input view.  The reference's image clean-up before that (rembg
+matting, kiui recentering - third-party CPU code) is not part of this build: pass an already prepared RGB image; `--synthetic`
+fabricates weights (and, without an image, the conditioning tensors) with the right shapes.
 """
 from __future__ import annotations
 
@@ -66,6 +67,32 @@ def get_batch(value_dict: dict, T: int, device: str):
     return batch, batch_uc
 
 
+CLIP_IMAGE_CONFIG = {   # reference: configs/embedder/clip_image.yaml with sgm. -> v3d_amd.sgm.
+    "target": "v3d_amd.sgm.modules.encoders.modules.FrozenOpenCLIPImagePredictionEmbedder",
+    "params": {"n_cond_frames": 1, "n_copies": 1,
+               "open_clip_embedding_config": {"target": "v3d_amd.sgm.modules.encoders.modules.FrozenOpenCLIPImageEmbedder",
+                                              "params": {"freeze": True}}}}
+
+
+def load_clip_model(device: str, ckpt_path: Optional[str] = None, synthetic: bool = False, clip_config=None):
+    """The reference's `clip_model` (V3D_512.py:146-153): FrozenOpenCLIPImagePredictionEmbedder with the
+    `conditioner.embedders.0.*` tensors of svd_xt.safetensors."""
+    clip_model = instantiate_from_config(clip_config or CLIP_IMAGE_CONFIG).eval()
+    if ckpt_path is not None:
+        if ckpt_path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(ckpt_path)
+        else:
+            sd = torch.load(ckpt_path, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+        clip_sd = {k.replace("conditioner.embedders.0.", ""): v for k, v in sd.items() if "conditioner.embedders.0" in k}
+        clip_model.load_state_dict(clip_sd)
+    elif not synthetic:
+        raise SystemExit("no --clip_checkpoint_path (svd_xt.safetensors) given for the OpenCLIP image embedder: pass --synthetic "
+                         "to run it on random-init weights")
+    return clip_model.to(device)
+
+
 @torch.no_grad()
 def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optional[str] = None, num_frames: Optional[int] = None,
                num_steps: Optional[int] = None, fps_id: int = 1, motion_bucket_id: int = 300, cond_aug: float = 0.02, seed: int = 23,
@@ -73,7 +100,7 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
                save: bool = False, cached_model: Any = None, border_ratio: float = 0.3, min_guidance_scale: float = 3.5,
                max_guidance_scale: float = 3.5, sigma_max: float = None, ignore_alpha: bool = False, *, config=None,
                cond_frames: torch.Tensor = None, cond_frames_without_noise: torch.Tensor = None, image: torch.Tensor = None,
-               synthetic: bool = False,
+               synthetic: bool = False, clip_checkpoint_path: Optional[str] = None, clip_config=None,
                height: int = 512, width: int = 512, model_channels: int = 320, vae_ch: int = 128):
     """Returns (frames uint8 [T, H, W, 3] on the host, model).  Keyword arguments up to `ignore_alpha` are the reference's."""
     num_frames = 18 if num_frames is None else num_frames       # the reference reads it from the guider config (18)
@@ -98,11 +125,19 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
         if checkpoint_path is None and synthetic and cached_model is None:
             synth.init_module_fast(model.first_stage_model.encoder, seed=3)
         cond_frames = model.first_stage_model.encode(image.to(device).float())
+    if cond_frames_without_noise is None and image is not None:
+        # native OpenCLIP image embedding (reference: configs/embedder/clip_image.yaml -> `clip_model(image)`, V3D_512.py:146-153,238);
+        # weights = the checkpoint's conditioner.embedders.0.* (svd_xt.safetensors), random-initialised under --synthetic
+        clip_model = getattr(model, "_v3d_clip_model", None)
+        if clip_model is None:
+            clip_model = load_clip_model(device, clip_checkpoint_path, synthetic, clip_config)
+            model._v3d_clip_model = clip_model
+        cond_frames_without_noise = clip_model(image.to(device).float())
     if cond_frames is None or cond_frames_without_noise is None:
         if not synthetic:
             raise SystemExit(
-                f"image front-end (matting / recentering / OpenCLIP embedding of {input_path}) is not part of this build: pass `image` "
-                "(or cond_frames [1,4,H/8,W/8]) and cond_frames_without_noise [1,1,1024] tensors, or --synthetic")
+                f"no conditioning for {input_path}: pass `image` [1,3,H,W] in [-1,1] (or cond_frames [1,4,H/8,W/8] and "
+                "cond_frames_without_noise [1,1,1024] tensors), or --synthetic")
         g = torch.Generator().manual_seed(seed)
         if cond_frames_without_noise is None:
             cond_frames_without_noise = torch.randn(1, 1, 1024, generator=g).to(device)
@@ -161,6 +196,7 @@ def main():
     ap.add_argument("--max_guidance_scale", type=float, default=3.5)
     ap.add_argument("--sigma_max", type=float, default=None)
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--clip_checkpoint_path", default=None, help="svd_xt.safetensors (conditioner.embedders.0.* = the OpenCLIP image tower)")
     a = ap.parse_args()
     image = None
     if os.path.isfile(a.input_path):
@@ -171,7 +207,8 @@ def main():
         image = torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1)[None].float() / 127.5 - 1.0
     frames, _ = sample_one(a.input_path, a.checkpoint_path, a.num_frames, a.num_steps, a.fps_id, a.motion_bucket_id, a.cond_aug, a.seed,
                            a.decoding_t, a.device, a.output_folder, save=a.save, min_guidance_scale=a.min_guidance_scale,
-                           max_guidance_scale=a.max_guidance_scale, sigma_max=a.sigma_max, config=a.config, synthetic=a.synthetic, image=image)
+                           max_guidance_scale=a.max_guidance_scale, sigma_max=a.sigma_max, config=a.config, synthetic=a.synthetic, image=image,
+                           clip_checkpoint_path=a.clip_checkpoint_path)
     print("frames", frames.shape, frames.dtype, "mean", float(frames.mean()))
 
 

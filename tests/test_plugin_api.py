@@ -57,6 +57,34 @@ def test_engine_from_config_end_to_end_tiny():
     assert any(k.startswith("first_stage_model.decoder.conv_out.time_mix_conv.weight") for k in sd)
 
 
+def test_entry_script_from_an_image_runs_the_native_front_end(tmp_path):
+    """sample_one(image=...) : OpenCLIP embedding (weights from a reference-format safetensors, conditioner.embedders.0.*) and VAE
+    encode of the input view feed the conditioner exactly as scripts/pub/V3D_512.py:146-153,238-243 does - emulated op backend."""
+    import importlib.util
+    from safetensors.torch import save_file
+    spec = importlib.util.spec_from_file_location("v3d_entry", os.path.join(ROOT, "scripts", "pub", "V3D_512.py"))
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    tiny_vit = dict(image_size=28, patch_size=14, width=32, layers=1, heads=2, mlp_ratio=2.0, embed_dim=1024)
+    clip_cfg = {"target": entry.CLIP_IMAGE_CONFIG["target"], "params": dict(entry.CLIP_IMAGE_CONFIG["params"])}
+    oc = dict(clip_cfg["params"]["open_clip_embedding_config"])
+    oc["params"] = dict(oc["params"], vision_cfg=tiny_vit)
+    clip_cfg["params"]["open_clip_embedding_config"] = oc
+    torch.manual_seed(0)
+    donor = entry.instantiate_from_config(clip_cfg)
+    ck = str(tmp_path / "svd_xt_like.safetensors")
+    save_file({"conditioner.embedders.0." + k: v.contiguous() for k, v in donor.state_dict().items()}, ck)
+    image = torch.rand(1, 3, 128, 128) * 2 - 1
+    with use_backend(EmulOps("cpu", exact=True)):
+        frames, model = entry.sample_one(num_frames=3, num_steps=2, device="cpu", synthetic=True, height=128, width=128, model_channels=64,
+                                         vae_ch=32, decoding_t=3, image=image, clip_checkpoint_path=ck, clip_config=clip_cfg)
+        want = donor(image)
+        got = model._v3d_clip_model(image)
+    assert frames.shape == (3, 128, 128, 3)
+    assert got.shape == (1, 1, 1024)
+    torch.testing.assert_close(got, want)
+
+
 def test_guider_and_discretizer_api():
     from v3d_amd.sgm.modules.diffusionmodules.discretizer import EDMDiscretization
     from v3d_amd.sgm.modules.diffusionmodules.guiders import LinearPredictionGuider

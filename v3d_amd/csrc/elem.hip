@@ -116,6 +116,95 @@ __global__ void heun_step_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// CLIP image front-end (FrozenOpenCLIPImageEmbedder.preprocess, sgm/modules/encoders/modules.py:645-657, + the patch unfold of
+// open_clip's VisionTransformer.conv1): kornia.geometry.resize(x, (S, S), "bicubic", align_corners=True, antialias) = [Gaussian
+// blur, reflect border, when down-scaling] then torch bicubic (A = -0.75, border taps clamped); (x + 1) / 2; (x - mean) / std;
+// output = the stride-P patches as GEMM rows: patches[b][py * G + px][c * P * P + ky * P + kx], zero-padded to Kpad columns.
+struct ClipPP {
+    const float* img;
+    bf16_t* out;
+    long long B;
+    int H, W, S, P, Kpad, ksy, ksx;
+    float sgy, sgx, mean[3], istd[3];
+};
+
+__device__ __forceinline__ float cubic_w(float t, int tap) {   // PyTorch upsample_bicubic2d coefficients, A = -0.75
+    const float A = -0.75f;
+    const float x = tap == 0 ? t + 1.f : tap == 1 ? t : tap == 2 ? 1.f - t : 2.f - t;
+    return (tap == 1 || tap == 2) ? ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f : ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+__device__ __forceinline__ int reflect_idx(int i, int n) {     // F.pad(mode="reflect"): no edge duplication
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i = i < 0 ? -i : i;
+    i %= period;
+    return i < n ? i : period - i;
+}
+
+__global__ void clip_preprocess_kernel(ClipPP p) {
+    const int G = p.S / p.P, PP = p.P * p.P;
+    const long long total = p.B * G * G * p.Kpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % p.Kpad);
+        const long long row = i / p.Kpad;
+        if (k >= 3 * PP) { p.out[i] = 0; continue; }
+        const int patch = (int)(row % (G * G));
+        const long long b = row / (G * G);
+        const int c = k / PP, ky = (k % PP) / p.P, kx = k % p.P;
+        const int oy = (patch / G) * p.P + ky, ox = (patch % G) * p.P + kx;
+        const float* im = p.img + ((b * 3 + c) * p.H) * (long long)p.W;
+        // align_corners=True source coordinates
+        const float sy = p.S > 1 ? oy * (float)(p.H - 1) / (float)(p.S - 1) : 0.f;
+        const float sx = p.S > 1 ? ox * (float)(p.W - 1) / (float)(p.S - 1) : 0.f;
+        const int iy = (int)floorf(sy), ix = (int)floorf(sx);
+        const float ty = sy - iy, tx = sx - ix;
+        float acc = 0.f;
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), p.H - 1);
+            const float wy = cubic_w(ty, a);
+            float rowacc = 0.f;
+            for (int bq = 0; bq < 4; ++bq) {
+                const int xx = min(max(ix - 1 + bq, 0), p.W - 1);
+                float v;
+                if (p.ksy == 1 && p.ksx == 1) {
+                    v = im[(long long)yy * p.W + xx];
+                } else {                                   // blurred pixel (yy, xx): separable Gaussian, normalised per axis
+                    float num = 0.f, wsy = 0.f;
+                    for (int gy = 0; gy < p.ksy; ++gy) {
+                        const float dy = (float)(gy - p.ksy / 2) + ((p.ksy & 1) ? 0.f : 0.5f);
+                        const float gwy = __expf(-dy * dy / (2.f * p.sgy * p.sgy));
+                        const int ry = reflect_idx(yy + gy - p.ksy / 2, p.H);
+                        float rx = 0.f, wsx = 0.f;
+                        for (int gx = 0; gx < p.ksx; ++gx) {
+                            const float dx = (float)(gx - p.ksx / 2) + ((p.ksx & 1) ? 0.f : 0.5f);
+                            const float gwx = __expf(-dx * dx / (2.f * p.sgx * p.sgx));
+                            rx += gwx * im[(long long)ry * p.W + reflect_idx(xx + gx - p.ksx / 2, p.W)];
+                            wsx += gwx;
+                        }
+                        num += gwy * (rx / wsx);
+                        wsy += gwy;
+                    }
+                    v = num / wsy;
+                }
+                rowacc += cubic_w(tx, bq) * v;
+            }
+            acc += wy * rowacc;
+        }
+        p.out[i] = f2bf(((acc + 1.f) * 0.5f - p.mean[c]) * p.istd[c]);
+    }
+}
+
+__global__ void gelu_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(gelu_erf_f(bflo(w[k])), gelu_erf_f(bfhi(w[k])));
+        reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ void axpb_kernel(const float* __restrict__ x, float a, float b, float* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = a * x[i] + b;
 }
@@ -243,6 +332,33 @@ extern "C" int v3d_heun_step(const float* x, const float* den, const float* eule
     V3D_REQUIRE(x && den && euler && den2 && sigma && next_sigma && out && n > 0 && chw > 0, "v3d_heun_step: bad args");
     hipLaunchKernelGGL(heun_step_kernel, dim3(nblocks(n * chw)), dim3(256), 0, ST, x, den, euler, den2, sigma, next_sigma, out, (long long)n, (long long)chw);
     return v3d_check_launch("v3d_heun_step");
+}
+
+extern "C" int v3d_clip_preprocess(const float* img, int64_t B, int32_t H, int32_t W, int32_t S, int32_t P, int32_t antialias,
+                                   const float* mean3, const float* std3, void* patches_bf16, int32_t Kpad, v3d_stream_t stream) {
+    V3D_REQUIRE(img && patches_bf16 && mean3 && std3 && B > 0 && H > 0 && W > 0 && S > 0 && P > 0 && S % P == 0, "v3d_clip_preprocess: bad args");
+    V3D_REQUIRE(Kpad >= 3 * P * P && Kpad % 8 == 0, "v3d_clip_preprocess: Kpad must be a multiple of 8 and >= 3 P^2");
+    ClipPP p;
+    p.img = img; p.out = (bf16_t*)patches_bf16; p.B = B; p.H = H; p.W = W; p.S = S; p.P = P; p.Kpad = Kpad;
+    // kornia.geometry.resize: antialias only when down-scaling; sigma = max((factor - 1) / 2, 0.001); kernel = int(max(4 sigma, 3)), made odd
+    const float fy = (float)H / (float)S, fx = (float)W / (float)S;
+    p.ksy = p.ksx = 1; p.sgy = p.sgx = 1.f;
+    if (antialias && (fy > 1.f || fx > 1.f)) {
+        p.sgy = fmaxf((fy - 1.f) * 0.5f, 0.001f);
+        p.sgx = fmaxf((fx - 1.f) * 0.5f, 0.001f);
+        p.ksy = (int)fmaxf(4.f * p.sgy, 3.f); if (p.ksy % 2 == 0) ++p.ksy;
+        p.ksx = (int)fmaxf(4.f * p.sgx, 3.f); if (p.ksx % 2 == 0) ++p.ksx;
+    }
+    for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.istd[c] = 1.f / std3[c]; }
+    const long long total = B * (long long)(S / P) * (S / P) * Kpad;
+    hipLaunchKernelGGL(clip_preprocess_kernel, dim3(nblocks(total)), dim3(256), 0, ST, p);
+    return v3d_check_launch("v3d_clip_preprocess");
+}
+
+extern "C" int v3d_gelu_bf16(const void* in, void* out, int64_t n, v3d_stream_t stream) {
+    V3D_REQUIRE(in && out && n > 0 && n % 8 == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0), "v3d_gelu_bf16: n must be a multiple of 8, pointers 16-byte aligned");
+    hipLaunchKernelGGL(gelu_bf16_kernel, dim3(nblocks(n / 8)), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, (long long)(n / 8));
+    return v3d_check_launch("v3d_gelu_bf16");
 }
 
 extern "C" int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream) {

@@ -64,6 +64,8 @@ SIGNATURES = {
     "v3d_cfg_combine": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "v3d_euler_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_heun_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "v3d_clip_preprocess": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "v3d_gelu_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "v3d_axpb_f32": (c_i32, [c_vp, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "v3d_blend_coefs": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
@@ -326,6 +328,26 @@ class HipOps(OpsBase):
         n = x.shape[0]
         self._check(self.lib.v3d_heun_step(x.data_ptr(), den.data_ptr(), euler.data_ptr(), den2.data_ptr(), sigma.data_ptr(),
                                            next_sigma.data_ptr(), out.data_ptr(), n, x.numel() // n, self._stream()), "v3d_heun_step")
+        return out
+
+    def clip_preprocess(self, img, size, patch, antialias, mean, std, kpad):
+        """img [B, 3, H, W] fp32 in [-1, 1] -> normalised, resized, unfolded patches [B * (size // patch)^2, kpad] bf16."""
+        self._req_c(img, torch.float32, "clip_preprocess.img")
+        B, Cc, H, W = img.shape
+        if Cc != 3:
+            raise RuntimeError("clip_preprocess: expected 3 channels")
+        g = size // patch
+        out = self.empty((B * g * g, kpad), torch.bfloat16, img.device)
+        m3 = (C.c_float * 3)(*[float(v) for v in mean])
+        s3 = (C.c_float * 3)(*[float(v) for v in std])
+        self._check(self.lib.v3d_clip_preprocess(img.data_ptr(), B, H, W, size, patch, int(bool(antialias)), C.cast(m3, C.c_void_p),
+                                                 C.cast(s3, C.c_void_p), out.data_ptr(), kpad, self._stream()), "v3d_clip_preprocess")
+        return out
+
+    def gelu(self, x, out=None):
+        self._req_c(x, torch.bfloat16, "gelu.x")
+        out = torch.empty_like(x) if out is None else out
+        self._check(self.lib.v3d_gelu_bf16(x.data_ptr(), out.data_ptr(), x.numel(), self._stream()), "v3d_gelu_bf16")
         return out
 
     def axpb_f32(self, x, a, b=0.0, out=None):

@@ -1,8 +1,9 @@
 """Conditioner front-end of the V3D_512 config (reference: sgm/modules/encoders/modules.py:42-206 AbstractEmbModel /
 GeneralConditioner, 229-234 IdentityEncoder, 937-953 ConcatTimestepEmbedderND).
 
-Runs once per sample before the sampling loop (not part of the timed hot path); the CLIP image embedder and the
-VAE encoder that produce `cond_frames_without_noise` / `cond_frames` are applied by the entry script, exactly as in
+Runs once per sample before the sampling loop (not part of the timed hot path); the CLIP image embedder
+(FrozenOpenCLIPImageEmbedder / FrozenOpenCLIPImagePredictionEmbedder, modules.py:594-752,1054-1072, below) and the VAE encoder
+that produce `cond_frames_without_noise` / `cond_frames` are applied by the entry script, exactly as in
 scripts/pub/V3D_512.py:238-243, and enter here through IdentityEncoder.
 """
 from __future__ import annotations
@@ -135,3 +136,89 @@ class GeneralConditioner(nn.Module):
         for e, r in zip(self.embedders, rates):
             e.ucg_rate = r
         return c, uc
+
+
+class FrozenOpenCLIPImageEmbedder(AbstractEmbModel):
+    """OpenCLIP ViT image embedding on the HIP kernels (modules.py:594-752).  Same constructor parameters; `arch` selects the
+    vision config (ViT-H-14 is the one SVD / V3D checkpoints carry; `vision_cfg` overrides it, e.g. for tests).  `version` names
+    pretrained weights in the reference - here weights come from the checkpoint's `conditioner.embedders.0.*` keys (or stay
+    random-initialised); nothing is downloaded."""
+
+    ARCHS = {"ViT-H-14": "VIT_H_14"}
+
+    def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", device="cuda", max_length=77, freeze=True, antialias=True,
+                 ucg_rate=0.0, unsqueeze_dim=False, repeat_to_max_len=False, num_image_crops=0, output_tokens=False,
+                 init_device=None, vision_cfg: Optional[Dict] = None):
+        super().__init__()
+        from . import open_clip_vit
+        if vision_cfg is None:
+            if arch not in self.ARCHS:
+                raise NotImplementedError(f"FrozenOpenCLIPImageEmbedder: arch {arch!r} (known: {sorted(self.ARCHS)})")
+            vision_cfg = getattr(open_clip_vit, self.ARCHS[arch])
+        if output_tokens or num_image_crops:
+            raise NotImplementedError("FrozenOpenCLIPImageEmbedder: output_tokens / num_image_crops are not used by SVD / V3D")
+        self.model = open_clip_vit.CLIPVisualOnly(**vision_cfg)
+        self.max_crops = num_image_crops
+        self.pad_to_max_len = False
+        self.repeat_to_max_len = repeat_to_max_len
+        self.device = device
+        self.max_length = max_length
+        if freeze:
+            self.freeze()
+        self.antialias = antialias
+        self.register_buffer("mean", torch.Tensor([0.48145466, 0.4578275, 0.40821073]), persistent=False)
+        self.register_buffer("std", torch.Tensor([0.26862954, 0.26130258, 0.27577711]), persistent=False)
+        self.ucg_rate = ucg_rate
+        self.unsqueeze_dim = unsqueeze_dim
+        self.output_tokens = output_tokens
+
+    def freeze(self):
+        self.model = self.model.eval()
+        for param in self.parameters():
+            param.requires_grad = False
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """The reference's `self.model` is a whole open_clip CLIP with only `.transformer` deleted, so checkpoints also carry its
+        text-side leftovers (token_embedding, positional_embedding, ln_final, text_projection, logit_scale, attn_mask): dropped."""
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith("model.") and not k.startswith("model.visual."))}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def encode_with_vision_transformer(self, img):
+        from ....engine.clip import run_clip_visual
+        vis = self.model.visual
+        return run_clip_visual(vis.packed(), img, self.antialias, self.mean.tolist(), self.std.tolist())
+
+    @torch.no_grad()
+    def forward(self, image, no_dropout=False):
+        z = self.encode_with_vision_transformer(image).to(image.dtype)
+        if self.ucg_rate > 0.0 and not no_dropout:
+            z = torch.bernoulli((1.0 - self.ucg_rate) * torch.ones(z.shape[0], device=z.device))[:, None] * z
+        if self.unsqueeze_dim:
+            z = z[:, None, :]
+        if self.repeat_to_max_len:
+            z_ = z[:, None, :] if z.dim() == 2 else z
+            return z_.expand(-1, self.max_length, -1).contiguous(), z
+        return z
+
+    def encode(self, text):
+        return self(text)
+
+
+class FrozenOpenCLIPImagePredictionEmbedder(AbstractEmbModel):
+    """modules.py:1054-1072: (b t) d -> b t d over n_cond_frames, each repeated n_copies times."""
+
+    def __init__(self, open_clip_embedding_config: Dict, n_cond_frames: int, n_copies: int):
+        super().__init__()
+        self.n_cond_frames = n_cond_frames
+        self.n_copies = n_copies
+        self.open_clip = instantiate_from_config(open_clip_embedding_config)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = {k: v for k, v in state_dict.items()
+              if not (k.startswith("open_clip.model.") and not k.startswith("open_clip.model.visual."))}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def forward(self, vid):
+        vid = self.open_clip(vid)
+        vid = vid.reshape(-1, self.n_cond_frames, vid.shape[-1])
+        return vid.repeat_interleave(self.n_copies, dim=0)
