@@ -196,6 +196,9 @@ int v3d_clip_preprocess(const float* img, int64_t B, int32_t H, int32_t W, int32
                         const float* mean3, const float* std3, void* patches_bf16, int32_t Kpad, v3d_stream_t stream);
 /* out = gelu(in), exact-erf form (nn.GELU in open_clip's ViT MLP), bf16, n % 8 == 0 */
 int v3d_gelu_bf16(const void* in, void* out, int64_t n, v3d_stream_t stream);
+/* Output stage (scripts/pub/V3D_512.py:286-303): frames x [n][C][S] fp32 in [-1,1] ->
+ * out [n][S][C] uint8 = (uint8)(clamp((x + 1) / 2, 0, 1) * 255), i.e. numpy's truncating astype; C <= 4.  Bit-exact with the reference. */
+int v3d_frames_to_uint8(const float* x, void* out_u8, int64_t n, int32_t C, int64_t S, v3d_stream_t stream);
 /* x[n][...] *= s  (sampling.py:50) ; generic y = a*x + b on fp32 */
 int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream);
 /* AlphaBlender coefficients (diffusionmodules/util.py:341-369): for mixer i with alpha_i = sigmoid(mix_factor_i)

@@ -260,6 +260,10 @@ class EmulOps(OpsBase):
         out[:, :3 * patch * patch] = pt.to(self.act_dtype)
         return out
 
+    def frames_to_uint8(self, x):
+        samples = torch.clamp((x.float() + 1.0) / 2.0, min=0.0, max=1.0)          # V3D_512.py:286-303, verbatim order of operations
+        return (samples.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous()
+
     def gelu(self, x, out=None):
         y = F.gelu(x.float()).to(x.dtype)
         if out is not None:

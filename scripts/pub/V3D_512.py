@@ -161,8 +161,11 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
     samples_z = model.sampler(denoiser, randn, cond=c, uc=uc)
     model.en_and_decode_n_samples_a_time = decoding_t
     samples_x = model.decode_first_stage(samples_z)
-    samples = torch.clamp((samples_x + 1.0) / 2.0, min=0.0, max=1.0)
-    frames = (samples.permute(0, 2, 3, 1) * 255).to(torch.uint8).cpu().numpy()
+    # output stage in one kernel (clamp, layout, uint8); `model.last_frames_u8` keeps the device tensor [T, H, W, 3] for consumers
+    # that take frames without a trip through an mp4 file (the reference hands them to recon/train_from_vid.py as a video)
+    from v3d_amd.ops import get_ops
+    model.last_frames_u8 = get_ops().frames_to_uint8(samples_x.float().contiguous())
+    frames = model.last_frames_u8.cpu().numpy()
     if save:
         folder = output_folder or "outputs/V3D_512"
         os.makedirs(folder, exist_ok=True)

@@ -222,6 +222,13 @@ def case_elementwise(hip, emu, dev, seed=0):
     hip.copy2d_bf16(src[:, 8:40], d_h[:, 16:48])
     emu.copy2d_bf16(src[:, 8:40], d_e[:, 16:48])
     res["copy2d"] = compare(d_h, d_e)
+    # output stage and the ViT activation: uint8 frames must be BIT-EXACT with the reference's clamp / * 255 / astype(uint8) chain
+    fr = (_rand(g, (3, 3, 24, 20), F32, 0.8, dev) * 1.2).contiguous()       # includes values outside [-1, 1]
+    u_h, u_e = hip.frames_to_uint8(fr), emu.frames_to_uint8(fr)
+    exact = bool((u_h == u_e).all()) and u_h.shape == (3, 24, 20, 3) and u_h.dtype == torch.uint8
+    res["frames_to_uint8_bitexact"] = (0.0, 1.0) if exact else (1.0, 0.0)
+    ge = _rand(g, (33, 40), device=dev) * 3
+    res["gelu"] = compare(hip.gelu(ge), emu.gelu(ge))
     return res
 
 

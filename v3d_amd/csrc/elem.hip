@@ -205,6 +205,20 @@ __global__ void gelu_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restri
     }
 }
 
+// Output stage (scripts/pub/V3D_512.py:286-303): clamp((x + 1) / 2, 0, 1) -> "t c h w -> t h w c" -> * 255 -> astype(uint8) (truncation),
+// one pass, frames stay on the device for the hand-off to the reconstruction stage.
+__global__ void frames_to_uint8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long long n, int Cc, long long S) {
+    const long long total = n * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / S, s = i - img * S;
+        for (int c = 0; c < Cc; ++c) {
+            float v = (x[(img * Cc + c) * S + s] + 1.0f) / 2.0f;
+            v = fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f;
+            out[i * Cc + c] = (unsigned char)(int)v;
+        }
+    }
+}
+
 __global__ void axpb_kernel(const float* __restrict__ x, float a, float b, float* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = a * x[i] + b;
 }
@@ -359,6 +373,12 @@ extern "C" int v3d_gelu_bf16(const void* in, void* out, int64_t n, v3d_stream_t 
     V3D_REQUIRE(in && out && n > 0 && n % 8 == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0), "v3d_gelu_bf16: n must be a multiple of 8, pointers 16-byte aligned");
     hipLaunchKernelGGL(gelu_bf16_kernel, dim3(nblocks(n / 8)), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, (long long)(n / 8));
     return v3d_check_launch("v3d_gelu_bf16");
+}
+
+extern "C" int v3d_frames_to_uint8(const float* x, void* out_u8, int64_t n, int32_t Cc, int64_t S, v3d_stream_t stream) {
+    V3D_REQUIRE(x && out_u8 && n > 0 && Cc > 0 && Cc <= 4 && S > 0, "v3d_frames_to_uint8: bad args");
+    hipLaunchKernelGGL(frames_to_uint8_kernel, dim3(nblocks(n * S)), dim3(256), 0, ST, x, (unsigned char*)out_u8, (long long)n, Cc, (long long)S);
+    return v3d_check_launch("v3d_frames_to_uint8");
 }
 
 extern "C" int v3d_axpb_f32(const float* x, float a, float b, float* out, int64_t n, v3d_stream_t stream) {

@@ -699,7 +699,6 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     const int wm = wave / WGN, wn = wave % WGN;
     const bf16_t* __restrict__ A = p.A;
     const bf16_t* __restrict__ W = p.W;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
     unsigned char* estage = lds + NS * STAGE_BYTES + wave * EPI_REGION;
 
     const int G = gridDim.x;
@@ -915,8 +914,8 @@ float* splitk_workspace(size_t floats, hipStream_t st) {
     static size_t cap = 0;
     if (floats > cap) {
         if (ws) {
-            hipStreamSynchronize(st);
-            hipFree(ws);
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(ws);
         }
         ws = nullptr;
         cap = 0;

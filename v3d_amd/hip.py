@@ -66,6 +66,7 @@ SIGNATURES = {
     "v3d_heun_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_clip_preprocess": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "v3d_gelu_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "v3d_frames_to_uint8": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp]),
     "v3d_axpb_f32": (c_i32, [c_vp, c_f32, c_f32, c_vp, c_i64, c_vp]),
     "v3d_blend_coefs": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp]),
@@ -342,6 +343,14 @@ class HipOps(OpsBase):
         s3 = (C.c_float * 3)(*[float(v) for v in std])
         self._check(self.lib.v3d_clip_preprocess(img.data_ptr(), B, H, W, size, patch, int(bool(antialias)), C.cast(m3, C.c_void_p),
                                                  C.cast(s3, C.c_void_p), out.data_ptr(), kpad, self._stream()), "v3d_clip_preprocess")
+        return out
+
+    def frames_to_uint8(self, x):
+        """x [n, C, H, W] fp32 in [-1, 1] -> [n, H, W, C] uint8 (device tensor)."""
+        self._req_c(x, torch.float32, "frames_to_uint8.x")
+        n, Cc, H, W = x.shape
+        out = torch.empty((n, H, W, Cc), dtype=torch.uint8, device=x.device)
+        self._check(self.lib.v3d_frames_to_uint8(x.data_ptr(), out.data_ptr(), n, Cc, H * W, self._stream()), "v3d_frames_to_uint8")
         return out
 
     def gelu(self, x, out=None):
