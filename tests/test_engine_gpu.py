@@ -113,6 +113,22 @@ def test_full_size_batch_independence(full_unet):
     assert rel <= 2e-2 and cos >= 0.9995, (rel, cos)
 
 
+def test_scene_config_batch_independence(full_unet):
+    """BASELINE.json configs[4] shape (the "scene" variant SURVEY.md 8d derives: T = 24 frames, 576 x 1024 -> 72 x 128 latents,
+    9216 / 2304 / 576 / 144 tokens per level - none of them the powers of two the kernels were tuned on): same property as above
+    at M = 442368 rows."""
+    T, H, W = 24, 72, 128
+    g = torch.Generator().manual_seed(13)
+    x, ts = torch.randn(2 * T, 8, H, W, generator=g).to(DEV), torch.randn(2 * T, generator=g).to(DEV)
+    ctx, y = torch.randn(2 * T, 1, 1024, generator=g).to(DEV), torch.randn(2 * T, 768, generator=g).to(DEV)
+    ioi = torch.zeros(2, T, device=DEV)
+    both = full_unet(x, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi).float()
+    half = full_unet(x[T:], ts[T:], context=ctx[T:], y=y[T:], num_video_frames=T, image_only_indicator=ioi[1:]).float()
+    assert both.shape == (2 * T, 4, H, W) and torch.isfinite(both).all()
+    rel, cos = rel_cos(both[T:], half)
+    assert rel <= 2e-2 and cos >= 0.9995, (rel, cos)
+
+
 def test_full_width_vs_oracle(full_unet):
     """Full-width network (320 channels, 64 x 64 latents) against the fp32 CPU oracle on a 2-image batch (1 frame, cfg 2)."""
     from oracle import sgm_oracle as O
