@@ -22,6 +22,19 @@
 #ifndef FF_STAMPS
 #define FF_STAMPS 127   // which of the per-tick timeline stamps the DBG build takes (each costs a few hundred cycles)
 #endif
+#ifndef FF_BIAS_LDS
+#define FF_BIAS_LDS 0   // 1: b1 rides an exec-masked LDS-DMA piece with its W1 slab and is read from LDS in slots 8..15; 0: eight global
+                        // loads at the tick top (measured: 468 vs 500 us - the LDS variant lengthens stage B's slots by more than it saves)
+#endif
+#ifndef FF_GFRONT
+#define FF_GFRONT 6     // GELU pieces executed at the tick top, beside the bias loads
+#endif
+#ifndef FF_AFIRST
+#define FF_AFIRST 0   // timing experiment: run stage A's MFMAs before stage B's inside a tick
+#endif
+#ifndef FF_BORDER
+#define FF_BORDER 0   // stage B MFMA order: 0 = k16 half outer (10 accumulators in turn, twice), 1 = accumulator outer (each twice in a row)
+#endif
 #ifndef FF_ABL
 #define FF_ABL 0   // timing experiments only (tools/ff_ablate.sh): 1 no GELU, 2 no DMA, 4 no LDS fragment reads in the slots, 8 no MFMA
 #endif
@@ -89,11 +102,13 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     constexpr int SROW = 128 + 16;             // staged row: 64 channels + pad
     constexpr int STAGE_REGION = 32 * SROW;
     static_assert(NO % 2 == 0, "staging geometry");
-    constexpr int RING = 2 * W1_BYTES + 2 * W2_BYTES;
+    constexpr int RING = 2 * W1_BYTES + 3 * W2_BYTES;   // W1 double-buffered, W2 three deep (see the tick description)
     constexpr int B2_OFF = RING + 4 * STAGE_REGION;   // b2 lives in LDS: the epilogue's only global loads are then its prefetches
-    constexpr int DBG_OFF = B2_OFF + C * 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[DBG_OFF + (DBG ? 8192 : 0)];
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(lds + DBG_OFF);
+    constexpr int B1_OFF = B2_OFF + C * 4;             // b1 of the two W1 slabs in the ring (256 B each), see load of `bu / bv` below
+    constexpr int LDS_BYTES = B1_OFF + 2 * 256;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    unsigned long long* dbg = g_ff_dbg;   // timeline build: stamps go straight to global memory (no LDS left: 159.3 of 160 KiB are in use)
     auto stamp = [&](int s_, int k) __attribute__((always_inline)) {
         if (DBG && ((FF_STAMPS >> k) & 1) && blockIdx.x == 0 && s_ >= 8 && s_ < 24 && (threadIdx.x & 63) == 0) dbg[((threadIdx.x >> 6) * 16 + (s_ - 8)) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
@@ -113,6 +128,13 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     // ---- weight-slab loader: 1-KiB pieces (16 rows x 64 B), lane l -> row l >> 2, 16-byte chunk (l & 3) ^ swz(row)
     const bufrsrc_t rsW1 = make_rsrc(p.W1, p.w1_bytes);
     const bufrsrc_t rsW2 = make_rsrc(p.W2, p.w2_bytes);
+    const bufrsrc_t rsB1 = make_rsrc(p.b1, (unsigned)(2 * p.hidden * 4));
+    // b1 travels with its W1 slab: 64 floats per slab, one exec-masked DMA piece (16 lanes x 16 B) by wave 0.  A plain global load
+    // of it from inside a tick queues behind ~1500 cycles of LDS-DMA traffic in the CU's memory pipeline and stage A waited for it.
+    auto issue_b1 = [&](int par, int slab) __attribute__((always_inline)) {
+        if (wave == 0 && lane < 16)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB1, (__attribute__((address_space(3))) void*)(lds + B1_OFF + par * 256), 16, lane * 16, slab * 256, 0, 0);
+    };
     const int prow = lane >> 2;
     const unsigned kchunk_b = (unsigned)(((lane & 3) ^ ff_swz(prow)) * 16);
     // piece q = wave + 4 i of W1 is LDS stage i, rows 16 wave ..; of W2 rows 16 (wave + 4 i) ..: one base VGPR per stream, the rest is
@@ -149,45 +171,66 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     //   stage A (parity PA): S = W1 slab . x^T, fragment q = 4 t + 2 kk + a                        the next 4 NT slots
     //   stage G (parity PG): the MFMA rows of a fragment are 8 g + 4 hi + c (g = reg >> 2, c = reg & 3): g even = value, g odd =
     //                        gate of hidden channel 8 (g >> 1) + 4 hi + c -> the lane's 8 values are one k16 operand of stage B
-    //   DMA (parity PD):     W1 slab ld1 -> w1ring[PD], W2 slab ld2 -> w2ring[PD]
-    // A parity of -1 switches the stage off.
-    auto tick = [&](auto pa_c, auto pg_c, auto pb_c, auto pd_c, int j) __attribute__((always_inline)) {
+    //   DMA:                 W1 slab ld1 -> w1ring[PD] (read next tick), W2 slab ld2 -> the W2 slot two ticks ahead of its use (D2)
+    // A parity of -1 switches the stage off.  W2 is three slots deep so that the fragments a tick starts with (stage B comes first)
+    // were made visible by the PREVIOUS barrier: the tick before prefetches them ahead of its own barrier (NEXTB), the first MFMAs of
+    // a tick then issue without the LDS round trip, and the end-of-tick wait is vmcnt(5) - this tick's five W2 pieces may still fly.
+    constexpr int NPD = 4;             // LDS fragment reads run this many slots ahead of their MFMAs
+    bf16x8 wf[NPD];                    // (carried across ticks: a tick prefetches the next one's first fragments)
+    int w2_wr_slot = 0, w2_rd_slot = 0;
+    auto tick = [&](auto pa_c, auto pg_c, auto pb_c, auto pd_c, auto d2_c, auto nextb_c, int j) __attribute__((always_inline)) {
         constexpr int PA = decltype(pa_c)::value, PG = decltype(pg_c)::value, PB = decltype(pb_c)::value, PDM = decltype(pd_c)::value;
-        constexpr int NB = PB >= 0 ? 2 * NO : 0, NA = PA >= 0 ? 4 * NT : 0, NS = 2 * NO + 4 * NT, NPD = 4;
+        constexpr bool D2 = decltype(d2_c)::value != 0, NEXTB = decltype(nextb_c)::value != 0;
+        constexpr int NB = PB >= 0 ? 2 * NO : 0, NA = PA >= 0 ? 4 * NT : 0, NS = 2 * NO + 4 * NT;
+        constexpr bool AF = FF_AFIRST && NB > 0 && NA > 0;
+        auto perm = [](int i) constexpr { return (FF_AFIRST && NB > 0 && NA > 0) ? (i < NA ? NB + i : i - NA) : i; };
         stamp(j, 0);
-        // the slab accumulators start from b1 (row 8 g + 4 hi + c of fragment a <-> register 4 g + c).  Loaded before the tick's DMAs
-        // (vmcnt retires in order), moved into the accumulators in the four slots before stage A's first MFMA
+        // the slab accumulators start from b1 (row 8 g + 4 hi + c of fragment a <-> register 4 g + c), read from its LDS copy in slots
+        // 8..15 and moved into the accumulators in the four slots before stage A's first MFMA
         float4 bu[4], bv[4];
-        if constexpr (PA >= 0) {
-            const float* bz = p.b1 + (j == nslab ? 0 : j + 1) * 64 + hi * 4;
+        const unsigned char* bz = FF_BIAS_LDS ? lds + B1_OFF + (PA < 0 ? 0 : PA) * 256 + hi * 16
+                                              : reinterpret_cast<const unsigned char*>(p.b1 + (j == nslab ? 0 : j + 1) * 64 + hi * 4);
+        constexpr bool BIAS_TOP = PA >= 0 && (!FF_BIAS_LDS || NB < 16 || AF);   // all eight 16-byte pieces at the tick top
+        if constexpr (BIAS_TOP) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bu[g] = *reinterpret_cast<const float4*>(bz + g * 8);
-                bv[g] = *reinterpret_cast<const float4*>(bz + 32 + g * 8);
+                bu[g] = *reinterpret_cast<const float4*>(bz + g * 32);
+                bv[g] = *reinterpret_cast<const float4*>(bz + 128 + g * 32);
             }
         }
-        int so1 = 0, so2 = 0;
+        const int b1_slab = ld1;
+        int so1 = 0, so2 = 0, w2wr = 0;
         if constexpr (PDM >= 0) {
             so1 = ld1 * 64 * C * 2;
-            so2 = ld2 * 64;
             if (++ld1 == nslab) ld1 = 0;
+        }
+        if constexpr (D2) {
+            so2 = ld2 * 64;
             if (++ld2 == nslab) ld2 = 0;
+            w2wr = w2_wr_slot * W2_BYTES;
+            if (++w2_wr_slot == 3) w2_wr_slot = 0;
+        }
+        // stage B reads the W2 slot w2_rd_slot (runtime: 3 does not divide the 2-tick unroll)
+        const int fb0 = foff0 + w2_rd_slot * W2_BYTES, fb1 = foff1 + w2_rd_slot * W2_BYTES;
+        if constexpr (PB >= 0) {
+            if (++w2_rd_slot == 3) w2_rd_slot = 0;
         }
         auto rd = [&](auto fc) __attribute__((always_inline)) -> bf16x8 {
             constexpr int f = decltype(fc)::value;
             if constexpr (f < NB)
-                return *reinterpret_cast<const bf16x8*>(w2ring + (PB < 0 ? 0 : PB) * W2_BYTES + (f % NO) * 2048 + ((f / NO) ? foff1 : foff0));
+                return *reinterpret_cast<const bf16x8*>(w2ring + (FF_BORDER ? f / 2 : f % NO) * 2048 + ((FF_BORDER ? f % 2 : f / NO) ? fb1 : fb0));
             else {
                 constexpr int q = f - NB;
                 return *reinterpret_cast<const bf16x8*>(w1ring + (PA < 0 ? 0 : PA) * W1_BYTES + (q >> 2) * W1_STAGE + (q & 1) * 2048 +
                                                         (((q >> 1) & 1) ? foff1 : foff0));
             }
         };
-        bf16x8 wf[NPD];
-        ff_static_for<0, NPD>([&](auto fc) __attribute__((always_inline)) {
-            if constexpr (decltype(fc)::value < NB + NA) wf[decltype(fc)::value] = rd(fc);
-        });
-        if constexpr (PA >= 0 && NB < 4) {   // no stage B to wait behind (first tick of a block): once per block, stall accepted
+        if constexpr (NB == 0 || AF) {   // no stage B: the first fragments are W1's, visible only after the barrier that just passed
+            ff_static_for<0, NPD>([&](auto fc) __attribute__((always_inline)) {
+                if constexpr (decltype(fc)::value < NB + NA) wf[decltype(fc)::value] = rd(std::integral_constant<int, perm(decltype(fc)::value)>{});
+            });
+        }
+        if constexpr (PA >= 0 && (NB < 16 || AF)) {   // no stage B to wait behind (first tick of a block): once per block, stall accepted
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 sA[PA][0][4 * g] = bu[g].x; sA[PA][0][4 * g + 1] = bu[g].y; sA[PA][0][4 * g + 2] = bu[g].z; sA[PA][0][4 * g + 3] = bu[g].w;
@@ -225,36 +268,50 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
                 }
             }
         };
-        constexpr int G_FRONT = 6;
+        constexpr int G_FRONT = FF_GFRONT;
         if constexpr (PG >= 0 && (FF_ABL & 1) == 0) {
             ff_static_for<0, G_FRONT>([&](auto mc) __attribute__((always_inline)) { gstep(mc); });
             __builtin_amdgcn_sched_barrier(0);
         }
         ff_static_for<0, NS>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (PA >= 0 && NB >= 4 && i + 4 >= NB && i < NB) {
+            if constexpr (PA >= 0 && !BIAS_TOP && i >= 8 && i < 16) {
+                if constexpr (i & 1) bv[(i - 8) >> 1] = *reinterpret_cast<const float4*>(bz + 128 + ((i - 8) >> 1) * 32);
+                else bu[(i - 8) >> 1] = *reinterpret_cast<const float4*>(bz + ((i - 8) >> 1) * 32);
+            }
+            if constexpr (FF_BIAS_LDS && PDM >= 0 && i == 2) issue_b1(PDM, b1_slab);
+            if constexpr (PA >= 0 && NB >= 16 && !AF && i + 4 >= NB && i < NB) {
                 constexpr int g = i + 4 - NB;
                 sA[PA][0][4 * g] = bu[g].x; sA[PA][0][4 * g + 1] = bu[g].y; sA[PA][0][4 * g + 2] = bu[g].z; sA[PA][0][4 * g + 3] = bu[g].w;
                 sA[PA][1][4 * g] = bv[g].x; sA[PA][1][4 * g + 1] = bv[g].y; sA[PA][1][4 * g + 2] = bv[g].z; sA[PA][1][4 * g + 3] = bv[g].w;
             }
             if constexpr (i < NB + NA) {
+                constexpr int pi = perm(i);
                 const bf16x8 w = wf[i % NPD];
                 if constexpr ((FF_ABL & 8) != 0) {
-                } else if constexpr (i < NB)
-                    acc2[i % NO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, hh[PB < 0 ? 0 : PB][i / NO], acc2[i % NO], 0, 0, 0);
+                } else if constexpr (pi < NB && (FF_ABL & 64) != 0) {
+                } else if constexpr (pi < NB) {
+                    constexpr int bo = (FF_ABL & 16) ? (pi & 1) : (FF_BORDER ? pi / 2 : pi % NO), ba = FF_BORDER ? pi % 2 : pi / NO;
+                    acc2[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, hh[PB < 0 ? 0 : PB][ba], acc2[bo], 0, 0, 0);
+                }
                 else {
-                    constexpr int q = i - NB;
+                    constexpr int q = pi - NB;
                     sA[PA < 0 ? 0 : PA][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xr[q >> 1], sA[PA < 0 ? 0 : PA][q & 1], 0, 0, 0);
                 }
-                if constexpr (i + NPD < NB + NA && (FF_ABL & 4) == 0) wf[i % NPD] = rd(std::integral_constant<int, i + NPD>{});
+                if constexpr (i + NPD < NB + NA && (FF_ABL & 4) == 0) wf[i % NPD] = rd(std::integral_constant<int, perm(i + NPD)>{});
             }
-            if constexpr (PDM >= 0 && i % 4 == 1 && (FF_ABL & 2) == 0) {
+#ifndef FF_DMA_LATE
+            if constexpr ((PDM >= 0 || D2) && i % 4 == 1 && (FF_ABL & 2) == 0) {
                 constexpr int k = i / 4;
-                if constexpr (k < PPW1)
+#else
+            if constexpr ((PDM >= 0 || D2) && (FF_ABL & 2) == 0 && ((i >= 20 && i < 40 && i % 2 == 0) || (i >= 40 && i < 55 && (i - 40) % 3 == 0))) {
+                constexpr int k = i < 40 ? (i - 20) / 2 : PPW1 + (i - 40) / 3;
+#endif
+                if constexpr (k < PPW1 && PDM >= 0)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(w1ring + PDM * W1_BYTES + k * W1_STAGE + wave * 1024),
                                                              16, (int)voff1, so1 + k * 64, 0, 0);
-                else if constexpr (k < PPW1 + PPW2)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(w2ring + PDM * W2_BYTES + (wave + 4 * (k - PPW1)) * 1024),
+                else if constexpr (k >= PPW1 && k < PPW1 + PPW2 && D2)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(w2ring + w2wr + (wave + 4 * (k - PPW1)) * 1024),
                                                              16, (int)voff2, so2 + (k - PPW1) * w2_step, 0, 0);
             }
             // stage G: 16 GELUs x 3 pieces over the tick's slots, plain fp32 (packed fp32 beside MFMAs costs more than it saves) and as
@@ -262,10 +319,11 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
             //   gelu(x) = relu(x) - |x| 2^-(z Q(z) + 1),  z = min(|x| / sqrt2, 4),  0.5 erfc(z) = 2^-(z Q(z) + 1)
             // Q: degree-3 fit of -log2(erfc(z)) / z weighted for the GELU error (|error| <= 8.6e-6 in fp32 Horner; the value is rounded
             // to bf16, 4e-3 relative, right after).  11 VALU + 1 transcendental per value.
-            // G_FRONT pieces run at the tick top, in the shadow of the first fragment reads' LDS latency; the rest is spread 7 per 10 slots
-            if constexpr (PG >= 0 && (FF_ABL & 1) == 0 && (i == 0 || (7 * i) / 10 != (7 * (i - 1)) / 10 || false)) {
-                constexpr int ms = G_FRONT + (i == 0 ? 0 : (7 * i) / 10);
-                if constexpr (ms < 48) gstep(std::integral_constant<int, ms>{});
+            // the 48 GELU pieces: G_FRONT of them at the tick top (0 now: the tick's first fragments are prefetched, nothing to wait for
+            // there), the rest spread evenly over the slots
+            if constexpr (PG >= 0 && (FF_ABL & 1) == 0) {
+                constexpr int NSTEP = 48 - G_FRONT;
+                if constexpr ((i == 0 || (NSTEP * i) / NS != (NSTEP * (i - 1)) / NS) && !((FF_ABL & 128) != 0 && i < 20)) gstep(std::integral_constant<int, G_FRONT + (NSTEP * i) / NS>{});
             }
             __builtin_amdgcn_sched_barrier(0);
 #ifdef FF_STAMP_B
@@ -279,10 +337,20 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
             hh[PG][0] = __builtin_bit_cast(bf16x8, hw0);
             hh[PG][1] = __builtin_bit_cast(bf16x8, hw1);
         }
+        if constexpr (NEXTB && !FF_AFIRST) {     // next tick's first stage-B fragments: their W2 slab became visible at the previous barrier
+            const int nb0 = foff0 + w2_rd_slot * W2_BYTES, nb1 = foff1 + w2_rd_slot * W2_BYTES;
+            ff_static_for<0, NPD>([&](auto fc) __attribute__((always_inline)) {
+                constexpr int f = decltype(fc)::value;
+                wf[f] = *reinterpret_cast<const bf16x8*>(w2ring + (FF_BORDER ? f / 2 : f) * 2048 + ((FF_BORDER && (f % 2)) ? nb1 : nb0));
+            });
+        }
 #ifndef FF_STAMP_B
         stamp(j, 1);
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next weights (and x) has landed
+        // this wave's share of W1 for the next tick (and x / residual prefetches, all older) has landed; the W2 pieces of this tick are
+        // the five youngest and are not needed before the tick after next
+        if constexpr (D2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef FF_STAMP_B
         stamp(j, 2);
 #endif
@@ -295,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     using I1 = std::integral_constant<int, 1>;
     using IX = std::integral_constant<int, -1>;
 
-    // ---- prologue: W1(0), W1(1) in flight (as the two ticks before a block would have left them), first x block, A(0) alone
+    // ---- prologue: W1(0), W1(1), W2(0) in flight (as the ticks before a block would have left them), first x block, A(0) alone
     long long blk = blockIdx.x;
     if (tid < C / 4) reinterpret_cast<float4*>(lds + B2_OFF)[tid] = reinterpret_cast<const float4*>(p.b2)[tid];
     {   // All CUs run identical blocks, so without this they stay in lockstep and their epilogues (and x fetches) hit HBM as one
@@ -312,10 +380,21 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
                                                  (int)voff1, par * 64 * C * 2 + k * 64, 0, 0);
     });
     ld1 = 2;
+    if (FF_BIAS_LDS) {
+        issue_b1(0, 0);
+        issue_b1(1, 1);
+    }
+    ff_static_for<0, PPW2>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int k = decltype(ic)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(w2ring + (wave + 4 * k) * 1024), 16, (int)voff2,
+                                                 k * w2_step, 0, 0);
+    });
+    ld2 = 1;
+    w2_wr_slot = 1;
     load_x(blk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    tick(I0{}, IX{}, IX{}, IX{}, -1);
+    tick(I0{}, IX{}, IX{}, IX{}, I0{}, I0{}, -1);
 
     // residual rows of one epilogue pass (64 channels): res1 coalesced (row c >> 3, 16-byte chunk c & 7), res2 in the MFMA layout
     u32x4 r1[2][4];
@@ -347,20 +426,20 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     while (true) {
         const long long mw0 = blk * 128 + wave * 32;
         bstamp(0);
-        tick(I1{}, I0{}, IX{}, I0{}, 0);                   // A(1) G(0)
+        tick(I1{}, I0{}, IX{}, I0{}, I1{}, I1{}, 0);       // A(1) G(0)            DMA W1(2) W2(1)
         bstamp(1);
         for (int j = 1; j + 2 < nslab; j += 2) {
-            tick(I0{}, I1{}, I0{}, I1{}, j);               // A(j+1) G(j) B(j-1)
-            tick(I1{}, I0{}, I1{}, I0{}, j + 1);
+            tick(I0{}, I1{}, I0{}, I1{}, I1{}, I1{}, j);   // A(j+1) G(j) B(j-1)   DMA W1(j+2) W2(j+1)
+            tick(I1{}, I0{}, I1{}, I0{}, I1{}, I1{}, j + 1);
         }
         // penultimate tick: no A (its x fragments are dead: fetch the next block's), then the boundary tick A'(0) + B(last)
         const long long nxt = blk + gridDim.x;
         bstamp(2);
         load_x(nxt < nblocks ? nxt : blk);
-        tick(IX{}, I1{}, I0{}, I1{}, nslab - 1);           // G(last) B(last-1)
+        tick(IX{}, I1{}, I0{}, I1{}, I0{}, I1{}, nslab - 1);   // G(last) B(last-1)    DMA W1'(1)
         bstamp(3);
         fetch_res(mw0, 0, r1[0], r2[0]);                   // the epilogue's first pass: in flight under the boundary tick
-        tick(I0{}, IX{}, I1{}, IX{}, nslab);               // A'(0) B(last)
+        tick(I0{}, IX{}, I1{}, IX{}, I1{}, I0{}, nslab);   // A'(0) B(last)        DMA W2'(0)
         bstamp(4);
 
         // ---- block epilogue: out = c_acc (acc + b2) + c1 res1 + c2 res2, 32 rows x 64 channels per staging pass
@@ -426,13 +505,6 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
         blk = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (DBG && blockIdx.x == 0 && (threadIdx.x & 63) < 16)
-        for (int k = 0; k < 8; ++k) g_ff_dbg[((threadIdx.x >> 6) * 16 + (threadIdx.x & 63)) * 8 + k] = dbg[((threadIdx.x >> 6) * 16 + (threadIdx.x & 63)) * 8 + k];
-    if (DBG && blockIdx.x == 0 && (threadIdx.x & 63) < 4)
-        for (int k = 0; k < 8; ++k) {
-            const int o = 512 + ((threadIdx.x >> 6) * 4 + (threadIdx.x & 63)) * 8 + k;
-            g_ff_dbg[o] = dbg[o];
-        }
 }
 
 }  // namespace
