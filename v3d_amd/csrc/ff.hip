@@ -29,6 +29,12 @@
 #ifndef FF_GFRONT
 #define FF_GFRONT 6     // GELU pieces executed at the tick top, beside the bias loads
 #endif
+#ifndef FF_XBAR
+#define FF_XBAR 1   // 1: this tick's five W2 pieces may stay in flight across the barrier (vmcnt(5)): they are first read two ticks later,
+                    //    behind the next barrier; the first stage-B fragments of a tick are read AFTER the barrier.  0: vmcnt(0) and the
+                    //    next tick's first fragments prefetched before the barrier (their slab was complete one barrier earlier).
+                    //    Same box: 485 vs 518 us - the LDS-DMA stream is what the tick waits for, letting it run across the barrier wins.
+#endif
 #ifndef FF_AFIRST
 #define FF_AFIRST 0   // timing experiment: run stage A's MFMAs before stage B's inside a tick
 #endif
@@ -172,9 +178,10 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     //   stage G (parity PG): the MFMA rows of a fragment are 8 g + 4 hi + c (g = reg >> 2, c = reg & 3): g even = value, g odd =
     //                        gate of hidden channel 8 (g >> 1) + 4 hi + c -> the lane's 8 values are one k16 operand of stage B
     //   DMA:                 W1 slab ld1 -> w1ring[PD] (read next tick), W2 slab ld2 -> the W2 slot two ticks ahead of its use (D2)
-    // A parity of -1 switches the stage off.  W2 is three slots deep so that the fragments a tick starts with (stage B comes first)
-    // were made visible by the PREVIOUS barrier: the tick before prefetches them ahead of its own barrier (NEXTB), the first MFMAs of
-    // a tick then issue without the LDS round trip, and the end-of-tick wait is vmcnt(5) - this tick's five W2 pieces may still fly.
+    // A parity of -1 switches the stage off.  W2 is three slots deep: the slab DMA'd in tick j is first read in tick j + 2, so its
+    // pieces (the last five a wave issues in a tick) may still be in flight at the tick's barrier - the wait there is vmcnt(5), and the
+    // LDS-DMA stream, which is what a tick ends up waiting for, never drains (FF_XBAR; the alternative use of the third slot,
+    // prefetching the next tick's first fragments ahead of the barrier, needs vmcnt(0) and measured 6 % slower).
     constexpr int NPD = 4;             // LDS fragment reads run this many slots ahead of their MFMAs
     bf16x8 wf[NPD];                    // (carried across ticks: a tick prefetches the next one's first fragments)
     int w2_wr_slot = 0, w2_rd_slot = 0;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
                                                         (((q >> 1) & 1) ? foff1 : foff0));
             }
         };
-        if constexpr (NB == 0 || AF) {   // no stage B: the first fragments are W1's, visible only after the barrier that just passed
+        if constexpr (NB == 0 || AF || FF_XBAR) {   // no stage B: the first fragments are W1's, visible only after the barrier that just passed
             ff_static_for<0, NPD>([&](auto fc) __attribute__((always_inline)) {
                 if constexpr (decltype(fc)::value < NB + NA) wf[decltype(fc)::value] = rd(std::integral_constant<int, perm(decltype(fc)::value)>{});
             });
@@ -300,9 +307,15 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
                 }
                 if constexpr (i + NPD < NB + NA && (FF_ABL & 4) == 0) wf[i % NPD] = rd(std::integral_constant<int, perm(i + NPD)>{});
             }
-#ifndef FF_DMA_LATE
+#if !defined(FF_DMA_LATE)
             if constexpr ((PDM >= 0 || D2) && i % 4 == 1 && (FF_ABL & 2) == 0) {
                 constexpr int k = i / 4;
+#elif FF_DMA_LATE == 2
+            if constexpr ((PDM >= 0 || D2) && (FF_ABL & 2) == 0 && i >= 20 && i < 50 && i % 2 == 0) {
+                constexpr int k = (i - 20) / 2;
+#elif FF_DMA_LATE == 3
+            if constexpr ((PDM >= 0 || D2) && (FF_ABL & 2) == 0 && i >= 4 && i < 49 && i % 3 == 1) {
+                constexpr int k = (i - 4) / 3;
 #else
             if constexpr ((PDM >= 0 || D2) && (FF_ABL & 2) == 0 && ((i >= 20 && i < 40 && i % 2 == 0) || (i >= 40 && i < 55 && (i - 40) % 3 == 0))) {
                 constexpr int k = i < 40 ? (i - 20) / 2 : PPW1 + (i - 40) / 3;
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
             hh[PG][0] = __builtin_bit_cast(bf16x8, hw0);
             hh[PG][1] = __builtin_bit_cast(bf16x8, hw1);
         }
-        if constexpr (NEXTB && !FF_AFIRST) {     // next tick's first stage-B fragments: their W2 slab became visible at the previous barrier
+        if constexpr (NEXTB && !FF_AFIRST && !FF_XBAR) {     // next tick's first stage-B fragments: their W2 slab became visible at the previous barrier
             const int nb0 = foff0 + w2_rd_slot * W2_BYTES, nb1 = foff1 + w2_rd_slot * W2_BYTES;
             ff_static_for<0, NPD>([&](auto fc) __attribute__((always_inline)) {
                 constexpr int f = decltype(fc)::value;
@@ -347,9 +360,9 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
 #ifndef FF_STAMP_B
         stamp(j, 1);
 #endif
-        // this wave's share of W1 for the next tick (and x / residual prefetches, all older) has landed; the W2 pieces of this tick are
-        // the five youngest and are not needed before the tick after next
-        if constexpr (D2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        // this wave's share of the next weights (and x / residual prefetches) has landed.  vmcnt(0), not vmcnt(5): the W2 pieces of
+        // this tick are read by the NEXT tick's pre-barrier prefetch, so the barrier below is the last one in front of their first use
+        if constexpr (FF_XBAR && D2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef FF_STAMP_B
         stamp(j, 2);
