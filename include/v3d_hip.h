@@ -103,6 +103,9 @@ int v3d_gemm(const v3d_gemm_args* args, v3d_stream_t stream);
  *   W1p [2*hidden][C] bf16, b1 [2*hidden] fp32: row 64 s + 32 a + 8 g + 4 h + c = the (g odd ? gate : value) row of hidden
  *                                               channel 32 s + 16 a + 8 (g >> 1) + 4 h + c
  *   W2p [C][hidden] bf16:                       W2p[o][32 s + 16 a + 8 h + 4 t + c] = W2[o][32 s + 16 a + 8 t + 4 h + c]
+ * and both matrices are then stored in the order the kernel's LDS-DMA stream reads them (ff_dma_tile_index): slabs (64 rows of W1p /
+ * 32 columns of W2p), a slab as 1-KiB pieces of 16 rows x 32 columns ordered (column block, row block), and inside a piece the 16-byte
+ * unit 4 r + p (r = row 0..15, p = 0..3) holds columns 8 (p ^ swz(r)) .. + 7 of row r, swz(r) = {0,2,3,1}[(r >> 2) & 3].
  * Requires C == 320 (the 64x64 level; wider levels use two v3d_gemm launches), M % 128 == 0, hidden % 64 == 0, hidden >= 128. */
 int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                  const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,

@@ -215,6 +215,12 @@ class EmulOps(OpsBase):
     def ff_fused(self, x, w1p, b1, w2p, b2, out, *, res1=None, res2=None, coef=None, coef_rpg=0, c_acc=1.0, c_res1=1.0, c_res2=1.0):
         M, Cc = x.shape
         hidden = w2p.shape[-1]
+        # the weight buffers arrive in the kernel's DMA tile order (v3d_amd/engine/packing.py ff_dma_tile_index): undo it first
+        from v3d_amd.engine.packing import ff_dma_tile_index
+        t1 = ff_dma_tile_index(2 * hidden, Cc, 64, Cc).to(x.device)
+        t2 = ff_dma_tile_index(Cc, hidden, Cc, 32).to(x.device)
+        w1l = torch.empty_like(w1p.reshape(-1)); w1l[t1] = w1p.reshape(-1); w1p = w1l.reshape(2 * hidden, Cc)
+        w2l = torch.empty_like(w2p.reshape(-1)); w2l[t2] = w2p.reshape(-1); w2p = w2l.reshape(Cc, hidden)
         # W1p rows: 64 s + 32 a + 8 g + 4 h + c = (g odd ? gate : value) of hidden channel 32 s + 16 a + 8 (g >> 1) + 4 h + c
         sraw = (x.float() @ w1p.float().t() + b1.float()).reshape(M, hidden // 16, 2, 2, 8)   # [.., g >> 1, g & 1, 4 h + c]
         h = (sraw[:, :, :, 0] * F.gelu(sraw[:, :, :, 1])).reshape(M, hidden)                   # natural channel order

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     unsigned char* const w2ring = lds + 2 * W1_BYTES;
     unsigned char* stage = lds + RING + wave * STAGE_REGION;
 
-    // ---- weight-slab loader: 1-KiB pieces (16 rows x 64 B), lane l -> row l >> 2, 16-byte chunk (l & 3) ^ swz(row)
+    // ---- weight-slab loader: 1-KiB pieces (16 rows x 64 B) whose LDS image is: lane l -> row l >> 2, 16-byte chunk (l & 3) ^ swz(row)
     const bufrsrc_t rsW1 = make_rsrc(p.W1, p.w1_bytes);
     const bufrsrc_t rsW2 = make_rsrc(p.W2, p.w2_bytes);
     const bufrsrc_t rsB1 = make_rsrc(p.b1, (unsigned)(2 * p.hidden * 4));
@@ -141,19 +141,13 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
         if (wave == 0 && lane < 16)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB1, (__attribute__((address_space(3))) void*)(lds + B1_OFF + par * 256), 16, lane * 16, slab * 256, 0, 0);
     };
-    const int prow = lane >> 2;
-    const unsigned kchunk_b = (unsigned)(((lane & 3) ^ ff_swz(prow)) * 16);
     // piece q = wave + 4 i of W1 is LDS stage i, rows 16 wave ..; of W2 rows 16 (wave + 4 i) ..: one base VGPR per stream, the rest is
     // a scalar offset (NOT the instruction's immediate: that one is added to the LDS address as well)
-#ifdef FF_DMA_CONTIG   // timing experiment (garbage results): every 1-KiB piece reads 1 KiB of CONTIGUOUS global memory
+    // the packed weights are stored in DMA-piece order (packing.py ff_dma_tile_index: 16 rows x 64 B, LDS swizzle pre-applied), so a
+    // piece is one contiguous KiB: lane l reads bytes 16 l .. 16 l + 15 of it (row-strided 64-byte segments DMA'd 24 % slower)
     const unsigned voff1 = (unsigned)(wave * 1024 + lane * 16);
     const unsigned voff2 = (unsigned)(wave * 1024 + lane * 16);
     const int w2_step = 4096;
-#else
-    const unsigned voff1 = (unsigned)(((wave * 16 + prow) * C) * 2) + kchunk_b;
-    const unsigned voff2 = (unsigned)(((wave * 16 + prow) * p.hidden) * 2) + kchunk_b;
-    const int w2_step = 64 * p.hidden * 2;
-#endif
     const int nslab = p.hidden / 32;
     int ld1 = 0, ld2 = 0;   // next slab of each weight stream (both wrap: the stream does not depend on the row block)
     // LDS fragment of 32 rows x 16 k out of 64-byte rows: row l31, logical 16-byte chunk 2 kk + hi
@@ -218,11 +212,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
             if (++ld1 == nslab) ld1 = 0;
         }
         if constexpr (D2) {
-#ifdef FF_DMA_CONTIG
-            so2 = ld2 * 20480;
-#else
-            so2 = ld2 * 64;
-#endif
+            so2 = ld2 * W2_BYTES;
             if (++ld2 == nslab) ld2 = 0;
             w2wr = w2_wr_slot * W2_BYTES;
             if (++w2_wr_slot == 3) w2_wr_slot = 0;
@@ -332,11 +322,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
 #endif
                 if constexpr (k < PPW1 && PDM >= 0)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(w1ring + PDM * W1_BYTES + k * W1_STAGE + wave * 1024),
-#ifdef FF_DMA_CONTIG
                                                              16, (int)voff1, so1 + k * 4096, 0, 0);
-#else
-                                                             16, (int)voff1, so1 + k * 64, 0, 0);
-#endif
                 else if constexpr (k >= PPW1 && k < PPW1 + PPW2 && D2)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (__attribute__((address_space(3))) void*)(w2ring + w2wr + (wave + 4 * (k - PPW1)) * 1024),
                                                              16, (int)voff2, so2 + (k - PPW1) * w2_step, 0, 0);
@@ -404,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     ff_static_for<0, 2 * PPW1>([&](auto ic) __attribute__((always_inline)) {
         constexpr int k = decltype(ic)::value % PPW1, par = decltype(ic)::value / PPW1;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (__attribute__((address_space(3))) void*)(w1ring + par * W1_BYTES + k * W1_STAGE + wave * 1024), 16,
-                                                 (int)voff1, par * 64 * C * 2 + k * 64, 0, 0);
+                                                 (int)voff1, par * 64 * C * 2 + k * 4096, 0, 0);
     });
     ld1 = 2;
     if (FF_BIAS_LDS) {

@@ -129,11 +129,37 @@ def ff_fused_k_perm(hidden: int) -> torch.Tensor:
     return (32 * s_ + 16 * a + 8 * t + 4 * h + c).reshape(-1)
 
 
+def ff_dma_tile_index(rows: int, cols: int, slab_rows: int, slab_cols: int) -> torch.Tensor:
+    """Flat indices (into a row-major [rows, cols] matrix) in the order v3d_ff_fused's weight stream reads them: the matrix is cut
+    into slabs of slab_rows x slab_cols, a slab into 1-KiB LDS-DMA pieces of 16 rows x 32 columns (64 B per row) ordered
+    (column block, row block), and inside a piece lane l = 4 * row + p carries the 8 columns of chunk p ^ swz(row) - the XOR swizzle
+    of the LDS image (ff.hip ff_swz) applied at pack time, so that a piece is 1 KiB of CONTIGUOUS memory (one buffer_load ... lds of
+    64 lanes x 16 B).  Exactly one of slab_rows / slab_cols differs from the full extent."""
+    assert rows % slab_rows == 0 and cols % slab_cols == 0 and slab_rows % 16 == 0 and slab_cols % 32 == 0
+    idx = []
+    swz = torch.tensor([0, 2, 3, 1])
+    r16, pp, e = torch.meshgrid(torch.arange(16), torch.arange(4), torch.arange(8), indexing="ij")
+    chunk = pp ^ swz[(r16 >> 2) & 3]
+    piece = r16 * cols + chunk * 8 + e                                           # [16, 4, 8] offsets inside a piece's 16 x 32 window
+    for sr in range(rows // slab_rows):
+        for sc in range(cols // slab_cols):
+            for cb in range(slab_cols // 32):
+                for rb in range(slab_rows // 16):
+                    idx.append(((sr * slab_rows + rb * 16) * cols + sc * slab_cols + cb * 32) + piece.reshape(-1))
+    return torch.cat(idx)
+
+
 def ff_fused_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
-    """Linear(C, 2 hidden).weight / .bias and Linear(hidden, C).weight -> (W1p, b1p, W2p) of v3d_ff_fused."""
+    """Linear(C, 2 hidden).weight / .bias and Linear(hidden, C).weight -> (W1p, b1p, W2p) of v3d_ff_fused: rows / columns in the
+    MFMA hand-over order (ff_fused_row_order / ff_fused_k_perm), then tiled into the DMA pieces of the kernel's weight stream."""
     hidden = w2.shape[-1]
+    C = w1.shape[1]
     ro = ff_fused_row_order(hidden).to(w1.device)
-    return _bf(w1[ro]), _f(b1[ro]), _bf(w2.reshape(-1, hidden)[:, ff_fused_k_perm(hidden).to(w2.device)])
+    w1p = w1[ro]                                                                  # [2 hidden, C]: slabs of 64 rows
+    w2p = w2.reshape(-1, hidden)[:, ff_fused_k_perm(hidden).to(w2.device)]        # [C, hidden]:   slabs of 32 columns
+    t1 = ff_dma_tile_index(2 * hidden, C, 64, C).to(w1.device)
+    t2 = ff_dma_tile_index(C, hidden, C, 32).to(w2.device)
+    return (_bf(w1p.reshape(-1)[t1].reshape(2 * hidden, C)), _f(b1[ro]), _bf(w2p.reshape(-1)[t2].reshape(C, hidden)))
 
 
 @dataclass
