@@ -212,15 +212,25 @@ class EmulOps(OpsBase):
                                         indexing="ij")
         return (32 * s_ + 16 * a + 8 * t + 4 * h + c).reshape(-1).to(device)
 
+    @staticmethod
+    def _ff_untile(w, rows, cols, slab_rows, slab_cols):
+        """v3d_ff_fused weight stream order -> row-major [rows, cols]: slabs of slab_rows x slab_cols, inside a slab 1-KiB pieces of
+        16 rows x 32 columns ordered (column block, row block), inside a piece the 16-byte unit 4 r + p holds columns
+        8 (p ^ swz(r)) .. + 7 of row r, swz(r) = {0,2,3,1}[(r >> 2) & 3]."""
+        t = w.reshape(rows // slab_rows, cols // slab_cols, slab_cols // 32, slab_rows // 16, 16, 4, 8)
+        r = torch.arange(16, device=w.device)
+        swz = torch.tensor([0, 2, 3, 1], device=w.device)[(r >> 2) & 3]
+        pos = (torch.arange(4, device=w.device)[None, :] ^ swz[:, None])            # [row, logical chunk] -> unit position
+        pos = pos[None, None, None, None, :, :, None].expand(*t.shape[:4], 16, 4, 8)
+        logical = torch.gather(t, 5, pos)                                            # [.., row, chunk, 8]
+        return logical.permute(0, 3, 4, 1, 2, 5, 6).reshape(rows, cols)
+
     def ff_fused(self, x, w1p, b1, w2p, b2, out, *, res1=None, res2=None, coef=None, coef_rpg=0, c_acc=1.0, c_res1=1.0, c_res2=1.0):
         M, Cc = x.shape
         hidden = w2p.shape[-1]
-        # the weight buffers arrive in the kernel's DMA tile order (v3d_amd/engine/packing.py ff_dma_tile_index): undo it first
-        from v3d_amd.engine.packing import ff_dma_tile_index
-        t1 = ff_dma_tile_index(2 * hidden, Cc, 64, Cc).to(x.device)
-        t2 = ff_dma_tile_index(Cc, hidden, Cc, 32).to(x.device)
-        w1l = torch.empty_like(w1p.reshape(-1)); w1l[t1] = w1p.reshape(-1); w1p = w1l.reshape(2 * hidden, Cc)
-        w2l = torch.empty_like(w2p.reshape(-1)); w2l[t2] = w2p.reshape(-1); w2p = w2l.reshape(Cc, hidden)
+        # the weight buffers arrive in the kernel's LDS-DMA piece order (include/v3d_hip.h): undo it first
+        w1p = self._ff_untile(w1p, 2 * hidden, Cc, 64, Cc)
+        w2p = self._ff_untile(w2p, Cc, hidden, Cc, 32)
         # W1p rows: 64 s + 32 a + 8 g + 4 h + c = (g odd ? gate : value) of hidden channel 32 s + 16 a + 8 (g >> 1) + 4 h + c
         sraw = (x.float() @ w1p.float().t() + b1.float()).reshape(M, hidden // 16, 2, 2, 8)   # [.., g >> 1, g & 1, 4 h + c]
         h = (sraw[:, :, :, 0] * F.gelu(sraw[:, :, :, 1])).reshape(M, hidden)                   # natural channel order

@@ -45,3 +45,17 @@ def test_fused_path_not_taken_off_spec():
     with use_backend(EmulOps("cpu", exact=True)):
         assert _pack_ff(FeedForward(640, mult=4, glu=True)).w2_fused is None
         assert _pack_ff(FeedForward(320, mult=0.1, glu=True)).w2_fused is None      # hidden 32
+
+
+def test_dma_tile_order_two_independent_statements_agree():
+    """packing.ff_dma_tile_index (index list, product side) and EmulOps._ff_untile (reshape / gather, test side) state the weight
+    stream order of include/v3d_hip.h independently: tiling with one and untiling with the other is the identity."""
+    from v3d_amd.engine.packing import ff_dma_tile_index
+    for rows, cols, sr, sc in ((2560, 320, 64, 320), (320, 1280, 320, 32), (512, 320, 64, 320), (320, 256, 320, 32)):
+        w = torch.randn(rows, cols)
+        tiled = w.reshape(-1)[ff_dma_tile_index(rows, cols, sr, sc)].reshape(rows, cols)
+        assert not torch.equal(tiled, w)
+        assert torch.equal(EmulOps._ff_untile(tiled, rows, cols, sr, sc), w)
+    # a piece is 1 KiB of consecutive elements: the first 512 bf16 of the stream are rows 0..15 x columns 0..31 of the matrix
+    idx = ff_dma_tile_index(128, 320, 64, 320)[:512]
+    assert set((idx // 320).tolist()) == set(range(16)) and set((idx % 320).tolist()) == set(range(32))
