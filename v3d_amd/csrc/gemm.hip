@@ -57,8 +57,7 @@ struct GP {
     int mt, nt;  // tile counts
     int split_n;         // > 1: split-K launch: blockIdx.y = split index = output slab (out = fp32 workspace [split][M][N], plain stores)
     const float* ws;     // finalize kernel only: the workspace to reduce
-    int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads, 1024 = v3 reads its
-                 // weight pieces as contiguous 1-KiB blocks (what a pre-tiled weight layout would cost; results are garbage)
+    int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads
 };
 
 // 64 KiB of zeros: an invalid (padding / tail) lane of the LDS-DMA points here and can still be advanced by k0 like a
@@ -731,10 +730,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
                 voff[i] = ok ? (unsigned)((s_ + p.a_row0) * p.lda * 2) + kchunk_b : kInvalid;
             } else {
                 const long long n = ld_n0 + (q - APIECES) * 16 + prow;
-                if (p.ablate & 1024)   // timing experiment (garbage results): W pieces as contiguous 1-KiB blocks of a pre-tiled weight
-                    voff[i] = (n < p.N) ? (unsigned)((((long long)tap * (p.N / 16) + (ld_n0 / 16 + (q - APIECES))) * (p.K / 32)) * 1024) + lane * 16 : kInvalid;
-                else
-                    voff[i] = (n < p.N) ? (unsigned)(((long long)tap * p.N + n) * p.ldw * 2) + kchunk_b : kInvalid;
+                voff[i] = (n < p.N) ? (unsigned)(((long long)tap * p.N + n) * p.ldw * 2) + kchunk_b : kInvalid;
             }
         }
     };
@@ -752,8 +748,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     auto issue_piece = [&](int stage, int i) __attribute__((always_inline)) {
         if (p.ablate & 4) return;
         const int q = wave + NW * i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)voff[i],
-                                                 (q >= APIECES && (p.ablate & 1024)) ? ld_k0 * 32 : ld_k0 * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)voff[i], ld_k0 * 2, 0, 0);
     };
     auto issue_advance = [&]() __attribute__((always_inline)) {
         ld_k0 += 32;
