@@ -133,14 +133,14 @@ def measure_gemm_roofline(step):
     # separate runs, calibrated on a copy of known size as MI355X_MICROARCH.md prescribes; tools/pmc_eval.py + pmc_traffic.py)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01l_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01m_pmc_traffic.json")))
         fams = [v for k, v in pmc["families"].items() if k.startswith("gemm_")]
         traffic = round(sum(v["read_GB_per_eval"] + v["write_GB_per_eval"] for v in fams) * 1e9 / sum(v["launches_per_eval"] for v in fams))
     except Exception:
         pass
     return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3<192x320 | 256x256> + gemm_kernel_v2<128x128 ...> (conv3x3 / convt3 / linear / GEGLU) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC, profiles/r01l_pmc_traffic.txt)",
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC, profiles/r01m_pmc_traffic.txt)",
             "algorithmic_bytes_per_launch": round(alg_bytes / n), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / n, 2),
             "algorithmic_tflop_per_sample": round(flops / 1e12, 2), "gemm_ms_per_sample": round(tot_ms, 2),
             "measured_on": "one extra instrumented sample after the timed region (HIP events per launch)"}
