@@ -78,6 +78,20 @@ __device__ __forceinline__ float gelu_erf_tight(float x) {
     return __builtin_fmaf(h, copysignf(r, x), h);               // 0.5 x (1 + erf(x / sqrt2))
 }
 
+// value * gelu(gate) for the GEGLU epilogues, in the fewest issue slots the bf16 result allows (the form ff.hip spreads over its MFMA
+// slots):  gelu(x) = relu(x) - |x| 2^-(z Q(z) + 1),  z = min(|x| / sqrt2, 4),  0.5 erfc(z) = 2^-(z Q(z) + 1),  Q = degree-3 fit of
+// -log2(erfc(z)) / z weighted for the GELU error: |gelu error| <= 8.6e-6 (fp32 Horner) against 4e-3 relative of the bf16 rounding that
+// follows.  10 VALU + 1 v_exp_f32 including the product with `value` (gelu_erf_tight above: 14 + 1).
+__device__ __forceinline__ float geglu_mul(float value, float x) {
+    const float z = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
+    float q = __builtin_fmaf(-1.664338751e-02f, z, 1.293501013e-01f);
+    q = __builtin_fmaf(q, z, 9.298687989e-01f);
+    q = __builtin_fmaf(q, z, 1.625731271e+00f);
+    q = __builtin_fmaf(q, z, 1.0f);
+    const float e = __builtin_amdgcn_exp2f(-q);
+    return value * (fmaxf(x, 0.0f) - fabsf(x) * e);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

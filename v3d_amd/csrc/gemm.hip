@@ -269,7 +269,7 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                         g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w;
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= (p.ablate & 16) ? g[r] : gelu_erf_tight(g[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = (p.ablate & 16) ? v[r] * g[r] : geglu_mul(v[r], g[r]);
                     (void)dummy;
                 }
                 const int jo = GEGLU ? (j >> 1) : j;
