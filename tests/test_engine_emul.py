@@ -99,3 +99,51 @@ def test_encoder(golden, exact, tol, cosmin):
         assert out.shape == golden["enc_moments"].shape
         rel, cos = rel_cos(out, golden["enc_moments"])
         assert rel <= tol and cos >= cosmin, (rel, cos)
+
+
+def test_decode_first_stage_chunked_product_side():
+    """SURVEY a-18 through the PRODUCT (DiffusionEngine.decode_first_stage, emulated kernels, exact fp32): chunks of
+    en_and_decode_n_samples_a_time frames are decoded with timesteps = len(chunk) (video_diffusion.py:182-210), which is not the full
+    decode (Appendix B-13); the 5-D "b t c h w" input form is reshaped back."""
+    from oracle import sgm_oracle as O
+    from v3d_amd import configs, synth
+    from v3d_amd.sgm.util import instantiate_from_config
+    T = 3
+    cfg = configs.v3d_512_config(num_frames=T, num_steps=2, model_channels=64, vae_ch=32)["model"]
+    cfg["params"]["en_and_decode_n_samples_a_time"] = 2
+    with use_backend(EmulOps("cpu", exact=True)):
+        eng = instantiate_from_config(cfg).eval()
+        eng.load_state_dict(synth.seeded_state_dict(eng, 1234), strict=True)
+        z = decoder_latents(T) * 0.18215
+        out = eng.decode_first_stage(z)
+        out5 = eng.decode_first_stage(z.reshape(1, T, 4, 8, 8))
+    dsd = {k: v.float() for k, v in eng.first_stage_model.decoder.state_dict().items()}
+    dcfg = synth.decoder_config(32)
+    ref = O.decode_first_stage(dsd, dcfg, z, eng.scale_factor, 2)
+    rel, cos = rel_cos(out, ref)
+    assert rel <= 5e-5 and cos >= 0.999999, (rel, cos)
+    full = O.decode_first_stage(dsd, dcfg, z, eng.scale_factor, T)
+    assert (ref - full).abs().max() > 1e-2
+    assert out5.shape == (1, T, 3, 64, 64) and torch.equal(out5[0], out)
+
+
+def test_load_last_embedder_is_refused():
+    from v3d_amd import configs
+    from v3d_amd.sgm.util import instantiate_from_config
+    cfg = configs.v3d_512_config(num_frames=3, num_steps=2, model_channels=64, vae_ch=32)["model"]
+    cfg["params"]["load_last_embedder"] = True
+    with use_backend(EmulOps("cpu", exact=True)), pytest.raises(NotImplementedError, match="load_last_embedder"):
+        instantiate_from_config(cfg)
+
+
+def test_unet_rejects_multi_token_context_and_missing_indicator():
+    """The collapsed cross-attention is exact for one context token only; learned_with_images needs the indicator (util.py:352-354)."""
+    p = TINY
+    T = p["T"]
+    _, _, _, x8, ts, ctx, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    with use_backend(EmulOps("cpu", exact=True)):
+        net = build_unet()
+        with pytest.raises(AssertionError, match="one token per image"):
+            net(x8, ts, context=torch.cat([ctx, ctx], dim=1), y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+        with pytest.raises(AssertionError, match="image_only_indicator is required"):
+            net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=None)

@@ -5,7 +5,7 @@ network evaluation (per-op bound 2e-2 is enforced in test_ops_gpu.py); sampler l
 import pytest
 import torch
 
-from conftest import rel_cos
+from conftest import rel_cos, full_inputs as _full_inputs  # noqa: F401  (`full_unet` is the session fixture of conftest.py)
 from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs, to_dev
 from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
@@ -82,22 +82,6 @@ def test_unet_vs_oracle_other_shapes(T, H, W, B2):
 
 
 # ---- BASELINE.json configs[1] sizes (width 320, 64 x 64 latents, 18 frames, cfg-doubled) --------------------------------------
-
-@pytest.fixture(scope="module")
-def full_unet():
-    from v3d_amd import synth
-    from v3d_amd.sgm.modules.diffusionmodules.video_model import VideoUNet
-    with torch.device(DEV):
-        net = VideoUNet(**synth.unet_config(320)).eval()
-    synth.init_module_fast(net, seed=1)
-    return net
-
-
-def _full_inputs(n, seed):
-    g = torch.Generator().manual_seed(seed)
-    return (torch.randn(n, 8, 64, 64, generator=g), torch.randn(n, generator=g), torch.randn(n, 1, 1024, generator=g),
-            torch.randn(n, 768, generator=g))
-
 
 def test_full_size_batch_independence(full_unet):
     """Size-independent property at the full benchmark size: the two cfg halves of the 36-image batch are independent samples,

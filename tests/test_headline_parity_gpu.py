@@ -1,0 +1,235 @@
+"""-m gpu: parity of the product path AT the headline configuration (BASELINE.json configs[1]) and over the whole sampler
+loop, against the fp32 CPU oracle (oracle/sgm_oracle.py, pinned to the reference by tests/test_oracle_pinned.py).
+
+  * test_headline_unet_eval_vs_oracle      width 320, 36 images (cfg 2 x T 18), 64 x 64 latents: ONE denoiser evaluation of the
+                                           benchmark itself (3-D GroupNorm over 18 frames, 18-token temporal attention at 8192 x 5
+                                           problems, the persistent 147456-row GEMM tiles) vs the oracle.
+  * test_rollout_25_steps_cosine_and_psnr  SURVEY.md 8d end-to-end bar at width 64: T = 18, 64 x 64 latents, 25 EulerEDM steps,
+                                           LinearPredictionGuider 4.5, DiffusionEngine.decode_first_stage -> 512 x 512 frames:
+                                           latent cosine >= 0.99 and decoded PSNR >= 35 dB; both numbers are printed and recorded.
+  * test_sampler_steps_teacher_forced      every denoiser call of the tiny 3-step samplers re-evaluated by the oracle ON THE HIP
+                                           TRAJECTORY'S OWN INPUTS (one-evaluation tolerance, so a 10 % kernel error inside the loop
+                                           cannot hide behind the guidance amplification), the guider / Euler / Heun arithmetic
+                                           recomputed in fp32 from the recorded tensors, and the HIP run compared with the bf16-mode
+                                           emulator (same rounding points, torch arithmetic).
+  * test_decode_first_stage_chunked        DiffusionEngine.decode_first_stage with en_and_decode_n_samples_a_time = 2 on T = 3
+                                           (reference video_diffusion.py:182-210: chunks see only their own frames) and the 5-D input
+                                           form; encode_first_stage with chunking.
+  * test_graph_replay_matches_eager        hipGraph capture of an evaluation replayed three times == eager (GroupNorm partial sums
+                                           are re-zeroed inside the graph).
+Tolerances: one evaluation cos >= 0.999 and max|err|/max|ref| <= 4e-2; 25-step latents cos >= 0.99; PSNR >= 35 dB.
+"""
+import time
+
+import pytest
+import torch
+
+from conftest import full_inputs, psnr, record_parity, rel_cos
+from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs, to_dev
+from v3d_amd import configs, synth
+from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+from v3d_amd.sgm.util import instantiate_from_config
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def test_headline_unet_eval_vs_oracle(full_unet):
+    from oracle import sgm_oracle as O
+    T = 18
+    x, ts, ctx, y = full_inputs(2 * T, 31)
+    ts = ts.abs() * 1.5 - 1.0                       # c_noise = ln(sigma) / 4 of the sigma schedule lies in [-1.6, 1.7]
+    ioi = torch.zeros(2, T)
+    out = full_unet(x.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi.to(DEV)).float().cpu()
+    sd = {k: v.detach().float().cpu() for k, v in full_unet.state_dict().items()}
+    t0 = time.time()
+    ref = O.unet_forward(sd, synth.unet_config(320), x, ts, ctx, y, T, ioi)
+    dt = time.time() - t0
+    rel, cos = rel_cos(out, ref)
+    per_frame = [rel_cos(out[i], ref[i])[1] for i in range(2 * T)]
+    record_parity("headline_unet_eval", {"images": 2 * T, "T": T, "width": 320, "latent": [64, 64], "cosine": round(cos, 6),
+                                         "max_rel_err": round(rel, 5), "min_per_image_cosine": round(min(per_frame), 6),
+                                         "oracle_seconds": round(dt, 1), "oracle_threads": torch.get_num_threads()})
+    assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
+    assert min(per_frame) >= 0.998, per_frame
+
+
+def _engine(T, steps, scale, mc=64, vae_ch=32, **kw):
+    cfg = configs.v3d_512_config(num_frames=T, num_steps=steps, min_scale=scale, max_scale=scale, model_channels=mc, vae_ch=vae_ch)["model"]
+    cfg["params"].update(kw)
+    eng = instantiate_from_config(cfg).eval()
+    eng.load_state_dict(synth.seeded_state_dict(eng, 1234), strict=True)
+    return eng.to(DEV)
+
+
+def test_rollout_25_steps_cosine_and_psnr():
+    from oracle import sgm_oracle as O
+    T, H, W, steps, scale = 18, 64, 64, 25, 4.5
+    eng = _engine(T, steps, scale)
+    noise, c, uc = synth.synthetic_conditioning(T, H, W, seed=23)
+    extra = {"image_only_indicator": torch.zeros(2, T, device=DEV), "num_video_frames": T}
+    z = eng.sampler(lambda i, s, cc: eng.denoiser(eng.model, i, s, cc, **extra), noise.clone().to(DEV), cond=to_dev(c, DEV), uc=to_dev(uc, DEV))
+    frames = eng.decode_first_stage(z)
+    assert frames.shape == (T, 3, 8 * H, 8 * W)
+    # ---- fp32 oracle of the same run ----
+    usd = {k: v.detach().float().cpu() for k, v in eng.model.diffusion_model.state_dict().items()}
+    dsd = {k: v.detach().float().cpu() for k, v in eng.first_stage_model.decoder.state_dict().items()}
+    ucfg, dcfg = synth.unet_config(64), synth.decoder_config(32)
+    ioi = torch.zeros(2, T)
+    t0 = time.time()
+    z_ref = O.sample_edm(lambda x8, cn, ctx, vec: O.unet_forward(usd, ucfg, x8, cn, ctx, vec, T, ioi), noise.clone(), c, uc, steps, T, scale, scale, 700.0)
+    t_samp = time.time() - t0
+    f_ref = O.decode_first_stage(dsd, dcfg, z_ref, eng.scale_factor, T)
+    rel_z, cos_z = rel_cos(z, z_ref)
+    rel_f, cos_f = rel_cos(frames, f_ref)
+    db = psnr(frames, f_ref)
+    # decoder alone on the oracle's latents (separates the decoder's own error from the sampler's)
+    f_dec = eng.decode_first_stage(z_ref.to(DEV))
+    db_dec = psnr(f_dec, f_ref)
+    # the uint8 frames a consumer sees (V3D_512.py:286-303): clamp((x+1)/2) * 255
+    to8 = lambda t: (torch.clamp((t.float().cpu() + 1.0) / 2.0, 0.0, 1.0) * 255).to(torch.uint8).float()
+    mse8 = ((to8(frames) - to8(f_ref)) ** 2).mean().item()
+    import math
+    db8 = float("inf") if mse8 == 0 else 10.0 * math.log10(255.0 ** 2 / mse8)
+    record_parity("rollout_25_steps_width64", {
+        "T": T, "latent": [H, W], "steps": steps, "cfg_scale": scale, "latent_cosine": round(cos_z, 6), "latent_max_rel_err": round(rel_z, 5),
+        "frames_cosine": round(cos_f, 6), "frames_psnr_db": round(db, 2), "frames_psnr_db_uint8": round(db8, 2),
+        "decoder_only_psnr_db": round(db_dec, 2), "oracle_sampler_seconds": round(t_samp, 1)})
+    assert cos_z >= 0.99, (rel_z, cos_z)
+    assert db >= 35.0, db
+
+
+@pytest.mark.parametrize("kind,key", SAMPLER_FIXTURES)
+def test_sampler_steps_teacher_forced(golden, kind, key):
+    from oracle import sgm_oracle as O
+    from oracle.ops_emul import EmulOps
+    from v3d_amd.ops import use_backend
+    p = TINY
+    T = p["T"]
+    noise, c, uc, *_ = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    net = build_unet(DEV)
+    sampler, den, wr = build_sampler(T, device=DEV, kind=kind), build_denoiser(), OpenAIWrapper(net)
+    extra = {"image_only_indicator": torch.zeros(2, T, device=DEV), "num_video_frames": T}
+    calls = []
+
+    def denoiser(i, s, cc):
+        out = den(wr, i, s, cc, **extra)
+        calls.append((i.detach().float().cpu().clone(), s.detach().float().cpu().clone(), {k: v.detach().float().cpu() for k, v in cc.items()},
+                      out.detach().float().cpu().clone()))
+        return out
+
+    z = sampler(denoiser, noise.clone().to(DEV), cond=to_dev(c, DEV), uc=to_dev(uc, DEV))
+    assert len(calls) == (2 * p["steps"] - 1 if kind.startswith("heun") else p["steps"])
+    # (1) every network evaluation of the loop, on its own inputs, against the fp32 oracle: one-evaluation tolerance
+    sd = {k: v.float().cpu() for k, v in net.state_dict().items()}
+    ucfg = synth.unet_config(p["model_channels"])
+    ioi = torch.zeros(2, T)
+    worst = (0.0, 1.0)
+    for inp, sig, cc, out in calls:
+        ref = O.denoise(lambda x8, cn, ctx, vec: O.unet_forward(sd, ucfg, x8, cn, ctx, vec, T, ioi), inp, sig, cc)
+        rel, cos = rel_cos(out, ref)
+        worst = (max(worst[0], rel), min(worst[1], cos))
+        assert rel <= 4e-2 and cos >= 0.999, (kind, rel, cos)
+    # (2) the elementwise sampler arithmetic (guider + Euler / Heun update), recomputed in fp32 from the recorded denoiser outputs
+    scale = O.guider_scale({"euler_linear": "linear", "heun_central": "central", "euler_vanilla": "vanilla"}[kind], T, p["min_scale"], p["max_scale"])
+    sigmas = O.edm_sigmas(p["steps"], sigma_max=p["sigma_max"])
+
+    def guided(out):
+        xu, xc = out.chunk(2)
+        return xu + scale.repeat(xu.shape[0] // T).reshape(-1, 1, 1, 1) * (xc - xu)
+
+    x = noise.clone() * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    it = iter(calls)
+    for i in range(p["steps"]):
+        inp, sig, _, out = next(it)
+        assert torch.allclose(inp[: x.shape[0]], x, rtol=1e-5, atol=1e-5 * float(x.abs().max()))
+        d = (x - guided(out)) / sigmas[i]
+        euler = x + (sigmas[i + 1] - sigmas[i]) * d
+        if kind.startswith("heun") and float(sigmas[i + 1]) > 0:
+            _, _, _, out2 = next(it)
+            d2 = (euler - guided(out2)) / sigmas[i + 1]
+            x = x + (sigmas[i + 1] - sigmas[i]) * (d + d2) / 2.0
+        else:
+            x = euler
+    rel_arith = ((z.float().cpu() - x).abs().max() / x.abs().max()).item()
+    assert rel_arith <= 2e-5, rel_arith
+    # (3) the same loop on the bf16-mode emulator (identical rounding points, torch arithmetic on the GPU)
+    with use_backend(EmulOps(DEV, exact=False)):
+        net_e = build_unet(DEV)
+        wr_e = OpenAIWrapper(net_e)
+        sampler_e = build_sampler(T, device=DEV, kind=kind)
+        z_e = sampler_e(lambda i, s, cc: den(wr_e, i, s, cc, **extra), noise.clone().to(DEV), cond=to_dev(c, DEV), uc=to_dev(uc, DEV))
+    rel_e, cos_e = rel_cos(z, z_e)
+    rel_g, cos_g = rel_cos(z, golden[key])
+    record_parity(f"sampler_{kind}", {"worst_eval_rel": round(worst[0], 5), "worst_eval_cos": round(worst[1], 6), "arith_rel": rel_arith,
+                                      "vs_bf16_emulator_rel": round(rel_e, 5), "vs_bf16_emulator_cos": round(cos_e, 6),
+                                      "vs_reference_fixture_rel": round(rel_g, 5), "vs_reference_fixture_cos": round(cos_g, 6)})
+    assert cos_e >= 0.995, (rel_e, cos_e)
+
+
+def test_decode_first_stage_chunked():
+    from oracle import sgm_oracle as O
+    T = 3
+    eng = _engine(T, 2, 2.0, en_and_decode_n_samples_a_time=2)
+    dsd = {k: v.detach().float().cpu() for k, v in eng.first_stage_model.decoder.state_dict().items()}
+    dcfg = synth.decoder_config(32)
+    z = decoder_latents(T) * 0.18215
+    out = eng.decode_first_stage(z.to(DEV))
+    ref = O.decode_first_stage(dsd, dcfg, z, eng.scale_factor, 2)          # chunks of 2 + 1 frames, timesteps = len(chunk)
+    rel, cos = rel_cos(out, ref)
+    assert out.shape == ref.shape and rel <= 4e-2 and cos >= 0.999, (rel, cos)
+    full = O.decode_first_stage(dsd, dcfg, z, eng.scale_factor, T)
+    assert (ref - full).abs().max() > 1e-2                                  # chunking changes the result (Appendix B-13) ...
+    rel_full, _ = rel_cos(out, full)
+    assert rel_full > rel * 2                                                # ... and the product follows the chunked semantics
+    out5 = eng.decode_first_stage(z.reshape(1, T, 4, 8, 8).to(DEV))          # "b t c h w" input form
+    assert out5.shape == (1, T, 3, 64, 64)
+    assert rel_cos(out5[0], out)[0] <= 2e-3          # (GroupNorm partial sums meet in fp32 atomics: run-to-run last-bit noise)
+    record_parity("decode_first_stage_chunked", {"T": T, "chunk": 2, "max_rel_err": round(rel, 5), "cosine": round(cos, 6)})
+    # encode_first_stage with chunking (video_diffusion.py:212-238); input_key != "latents" runs the VAE encoder + regulariser, whose
+    # posterior sample draws torch.randn(mean.shape) on the CPU generator per chunk (distributions.py:37-41)
+    eng.input_key = "frames"
+    esd = {k: v.detach().float().cpu() for k, v in eng.first_stage_model.encoder.state_dict().items()}
+    img = torch.rand(3, 3, 64, 48, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    torch.manual_seed(5)
+    zz = eng.encode_first_stage(img.to(DEV))
+    torch.manual_seed(5)
+    refs = []
+    for i in range(0, 3, 2):
+        mean, logvar = torch.chunk(O.encoder_forward(esd, synth.encoder_config(32), img[i:i + 2]), 2, dim=1)
+        refs.append(mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * torch.randn(mean.shape))
+    zref = eng.scale_factor * torch.cat(refs, dim=0)
+    rel, cos = rel_cos(zz, zref)
+    assert zz.shape == zref.shape and rel <= 4e-2 and cos >= 0.999, (rel, cos)
+
+
+def test_graph_replay_matches_eager():
+    from v3d_amd.engine.graph import graphed
+    p = TINY
+    T = p["T"]
+    _, _, _, x8, ts, ctx, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    net = build_unet(DEV)
+    ioi = torch.zeros(2, T, device=DEV)
+
+    def ev(x, t, cx, yy):
+        return net(x, t, context=cx, y=yy, num_video_frames=T, image_only_indicator=ioi)
+
+    args = (x8.to(DEV), ts.to(DEV), ctx.to(DEV), y.to(DEV))
+    eager = ev(*args).float().clone()
+    g = graphed(ev, enabled=True)
+    for rep in range(3):
+        rel, cos = rel_cos(g(*args), eager)     # (not bit-equal: GroupNorm partial sums meet in fp32 atomics, order varies run to run)
+        assert rel <= 2e-3 and cos >= 0.99999, f"graph replay {rep} differs from eager: rel {rel} cos {cos}"
+    # other inputs through the same captured graph
+    args2 = tuple(a * 0.5 for a in args)
+    rel, cos = rel_cos(g(*args2), ev(*args2))
+    assert rel <= 2e-3 and cos >= 0.99999, (rel, cos)
+    # the decoder graph (3-D GroupNorm statistics spanning T frames)
+    dec = build_decoder(DEV)
+    z = decoder_latents(T, DEV)
+    gd = graphed(lambda zz: dec(zz, timesteps=T), enabled=True)
+    want = dec(z, timesteps=T).float().clone()
+    for rep in range(3):
+        rel, cos = rel_cos(gd(z), want)
+        assert rel <= 2e-3 and cos >= 0.99999, f"decoder graph replay {rep} differs: rel {rel} cos {cos}"

@@ -17,6 +17,8 @@
 // LDS-DMA destination is lane-linear) so every ds_read_b128 lane group hits 16 distinct 16-byte slots.
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -906,24 +908,28 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GP p) {
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + m * p.ldo + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
 }
 
-// library-owned fp32 workspace of the split-K path (one per process, single-stream use like every other entry point; grows on
-// demand).  Partials are written with plain stores, one slab per split: fp32 atomics into one slab were tried first and
+// library-owned fp32 workspaces of the split-K path: ONE PER STREAM (two streams splitting at the same time must not share partial
+// sums), grow-only, and a retired (outgrown) slab is never freed: a HIP graph captured earlier may still replay launches that
+// point into it.  Growth is geometric, so the retired slabs add up to less than twice the live one.  A request that would have to
+// allocate while its stream is being captured returns nullptr (hipMalloc is illegal in a capture) and the caller falls back to
+// the unsplit launch.  Partials are written with plain stores, one slab per split: fp32 atomics into one slab were tried first and
 // made the launch 1.4-2.5x slower than not splitting at all (8.8 M atomics per 8x8 conv).
 float* splitk_workspace(size_t floats, hipStream_t st) {
-    static float* ws = nullptr;
-    static size_t cap = 0;
-    if (floats > cap) {
-        if (ws) {
-            (void)hipStreamSynchronize(st);
-            (void)hipFree(ws);
-        }
-        ws = nullptr;
-        cap = 0;
+    struct Slab { float* ptr; size_t cap; };
+    static std::mutex mu;
+    static std::map<hipStream_t, Slab> slabs;
+    std::lock_guard<std::mutex> lock(mu);
+    Slab& s = slabs[st];
+    if (floats > s.cap) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
         const size_t want = floats + floats / 2;
-        if (hipMalloc(reinterpret_cast<void**>(&ws), want * sizeof(float)) != hipSuccess) return nullptr;
-        cap = want;
+        float* fresh = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(float)) != hipSuccess) return nullptr;
+        s.ptr = fresh;      // the old slab stays allocated (see above)
+        s.cap = want;
     }
-    return ws;
+    return s.ptr;
 }
 
 int impl_choice() {

@@ -127,6 +127,7 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
     Returns an [n, out_channels, H, W] fp32 view of the channels-last result."""
     ops = get_ops()
     n, _, H, W = x.shape
+    ops.begin_evaluation(x.device)
     T = int(num_video_frames) if num_video_frames is not None else 1
     if shard is not None:
         T = shard.T_local
@@ -146,11 +147,16 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
         lab = ops.linear(ops.silu_add(ops.linear(yb, w0, b0, out_dtype=F32)), w2, b2, out_dtype=F32)
     semb = ops.silu_add(e, lab)                                             # SiLU(emb): input of every emb_layers
     emb_all = ops.linear(semb, pk.emb_w, pk.emb_b, out_dtype=F32)           # [n, sum Cout]
+    # the collapsed cross-attention (W_ov folded at pack time, engine/packing.py) is exact for ONE context token only
+    assert context is not None and context.dim() == 3 and context.shape[0] == n and context.shape[1] == 1, \
+        f"context must be [n={n}, 1, context_dim] (one token per image, as V3D / SVD condition), got {None if context is None else tuple(context.shape)}"
     c2 = context.reshape(n, -1)
     c0 = c2[::T] if context_frame0 is None else context_frame0.reshape(B, -1)   # time_context = context[::timesteps]
     cb = _cast_rows_bf16(ops, torch.cat([c2, c0.to(c2.dtype)], dim=0))
     ctx_all = ops.linear(cb, pk.ctx_w, pk.ctx_b, out_dtype=F32)            # [n + B, sum C]
     ioi = None
+    # merge_strategy="learned_with_images" needs the indicator (AlphaBlender.get_alpha asserts it, util.py:352-354)
+    assert not pk.uses_ioi or image_only_indicator is not None, "image_only_indicator is required by merge_strategy='learned_with_images'"
     if pk.uses_ioi and image_only_indicator is not None:
         ioi = image_only_indicator.reshape(-1).float().contiguous()
         assert ioi.numel() == n, f"image_only_indicator has {ioi.numel()} entries for {n} images"

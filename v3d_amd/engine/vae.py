@@ -44,6 +44,7 @@ def run_decoder(pk: VAEPack, z: torch.Tensor, T: int, shard=None) -> torch.Tenso
     """z [(b t), zc, h, w] fp32 -> [(b t), out_ch, 8h, 8w] fp32 (NCHW, like the reference)."""
     ops = get_ops()
     n, _, H, W = z.shape
+    ops.begin_evaluation(z.device)
     assert n % T == 0, f"{n} latent frames is not a multiple of timesteps={T}"
     env = Env(ops=ops, shard=shard)
     g = Geo(n=n, B=n // T, T=T, H=H, W=W)
@@ -77,6 +78,7 @@ def run_encoder(pk: VAEEncPack, x: torch.Tensor) -> torch.Tensor:
     Same kernels, layout and precision policy as the decoder."""
     ops = get_ops()
     n, _, H, W = x.shape
+    ops.begin_evaluation(x.device)
     env = Env(ops=ops, shard=None)
     g = Geo(n=n, B=n, T=1, H=H, W=W)
     h = ops.nchw_to_nhwc_bf16(x.float().contiguous(), 1.0, pk.in_pad)

@@ -77,10 +77,30 @@ class OpsBase:
 
     _ZERO_ARENA_FLOATS = 8 << 20   # 32 MiB: about one network evaluation's worth of GroupNorm partial-sum buffers
 
+    def begin_evaluation(self, device):
+        """Called at the top of every network evaluation (U-Net, VAE decoder / encoder, CLIP tower): rewinds the zero-initialised
+        scratch arena of `zeros_f32_pooled` and re-zeros the part the previous evaluation dirtied with ONE fill.  The fill is an
+        ordinary stream operation, so a HIP-graph capture of the evaluation records it as its first node and every replay starts
+        from zeroed GroupNorm partial sums (the first version zeroed a slice once, outside the capture: replays accumulated on top
+        of the sums of the capture run).  Slices handed out before the rewind must not be used afterwards - they are
+        evaluation-local by construction (statistics live between a stats and an apply kernel)."""
+        key = str(device)
+        arenas = self.__dict__.setdefault("_zero_arenas", {})
+        arena = arenas.get(key)
+        if arena is None:
+            return
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            arena[0].zero_()       # the recorded fill must cover whatever the captured evaluation dirties on every replay
+        elif arena[1] > 0:
+            arena[0][:arena[1]].zero_()
+        arena[1] = 0
+
     def zeros_f32_pooled(self, shape, device):
-        """Zero-initialised fp32 scratch carved out of a pre-zeroed arena: one fill kernel per ~100 requests instead of
-        one per request (the per-GroupNorm `torch.zeros` fills were 3000 launches / 14 ms per sample in the rocprof trace).
-        Slices are never handed out twice; an exhausted arena is simply replaced (its slices keep it alive)."""
+        """Zero-initialised fp32 scratch carved out of a pre-zeroed arena: one fill kernel per evaluation instead of one per
+        request (the per-GroupNorm `torch.zeros` fills were 3000 launches / 14 ms per sample in the rocprof trace).  A slice is
+        handed out once per evaluation (`begin_evaluation` rewinds); an exhausted arena is replaced by a fresh, larger one (the
+        old slices keep the old storage alive) - except under stream capture, where a new allocation would belong to the
+        graph's private pool: there the request falls back to its own `torch.zeros` (a memset node)."""
         n = 1
         for d in shape:
             n *= int(d)
@@ -88,6 +108,8 @@ class OpsBase:
         arenas = self.__dict__.setdefault("_zero_arenas", {})
         arena = arenas.get(key)
         if arena is None or arena[1] + n > arena[0].numel():
+            if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return torch.zeros(shape, dtype=torch.float32, device=device)
             arena = [torch.zeros(max(n, self._ZERO_ARENA_FLOATS), dtype=torch.float32, device=device), 0]
             arenas[key] = arena
         t = arena[0][arena[1]:arena[1] + n].view(shape)

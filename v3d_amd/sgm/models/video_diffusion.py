@@ -43,7 +43,11 @@ class DiffusionEngine(nn.Module):
         self.scale_factor = scale_factor
         self.disable_first_stage_autocast = disable_first_stage_autocast
         self.no_cond_log = no_cond_log
-        self.load_last_embedder = load_last_embedder
+        if load_last_embedder:
+            # the reference re-creates the last conditioner embedder's projection from the checkpoint when keys are missing
+            # (video_diffusion.py:165-168, _load_last_embedder); silently skipping that would load different weights
+            raise NotImplementedError("load_last_embedder=True (video_diffusion.py:165-168) is not supported by this build")
+        self.load_last_embedder = False
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, from_scratch)
         self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
