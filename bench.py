@@ -1,24 +1,38 @@
 """bench.py — V3D_512 dense-multi-view generation throughput on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--shard replica|frames]     (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 One "step" = one pass of the hot path over one batch: a full 18-frame sample — 25 EulerEDM steps (each one
 denoiser evaluation of the cfg-doubled 36-image batch through VideoUNet) followed by the 18-frame VideoDecoder decode
 (BASELINE.json configs[1]: random-init SVD-XT weights, 1x18x4x64x64 latent, 25 steps, cfg on, bf16, synthetic inputs
-already resident in HBM).  metric = multi-view frames / second; N ranks each generate their own sample (independent
-inputs, no data-path collective -> weak scaling), value = N * K * 18 / max-over-ranks time.
+already resident in HBM).  metric = multi-view frames / second.
+
+Multi-GPU modes (--gpus N > 1):
+  --shard replica (default)  every rank generates its own sample (independent inputs, no data-path collective): weak scaling,
+                             value = N * K * 18 / max-over-ranks time.  After the timed region the SAME job is also measured in
+                             frame-sharded mode and reported as the extra object "frame_shard" (it never changes `value`).
+  --shard frames             BASELINE.json configs[2]/[3]: ONE sample, its 18 frames sharded over the N ranks for the whole path
+                             (v3d_amd/dist.py: K|V exchange before each temporal attention, +-1 frame halos for the (3,1,1) convs,
+                             all-reduced 3-D GroupNorm sums; weights replicated): strong scaling, value = K * 18 / max-over-ranks time.
 
 Also reported on the same JSON line:
-  roofline     — for the dominant kernel family (the tap-GEMM `gemm_kernel<...>`: conv3x3 / temporal conv / linear):
-                 algorithmic FLOPs (2*M*N*K*taps of every launch of one sample) / summed launch durations measured with
-                 HIP events on the launch stream in one extra instrumented sample, against the dense bf16 MFMA peak.
+  roofline     — for the dominant kernel family (the `v3d_gemm` launches + the fused feed-forward): algorithmic FLOPs / summed launch
+                 durations measured LIVE with HIP events on the launch stream in one extra instrumented sample, against the dense bf16
+                 MFMA peak; `per_kernel` lists every timed op family of that sample with its own bound (mfma / hbm), achieved rate and
+                 fraction of that bound's peak.  `traffic` (HBM-side bytes per launch) comes from the committed rocprofv3 PMC passes
+                 (PMC counters cannot be collected inside this process); `traffic_profile` says which profile and whether the kernel
+                 sources changed since it was taken.
   cpu_baseline — the fp32 CPU oracle (oracle/sgm_oracle.py, kind "port") timed on the host cores on a bounded sample of
-                 the same workload and extrapolated (rank 0, N = 1 only).
+                 the same workload and extrapolated (rank 0, N = 1 only), plus parity of the HIP path against it: one full-width
+                 evaluation on the timed inputs and the 25-step width-64 rollout (latent cosine, decoded-frame PSNR).
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -33,12 +47,22 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X (MI355X_MICROARCH.
 PEAK_HBM_GBPS = 8000.0
 F_UNET_TFLOP = 45.677          # algorithmic FLOPs of one denoiser evaluation (reference graph, cfg batch 36)
 F_VAE_TFLOP_PER_FRAME = 3.043
+PMC_PROFILE = "r02_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
 
 T_FRAMES, STEPS, CFG, LAT = 18, 25, 4.5, 64
 P = "v3d_amd.sgm.modules.diffusionmodules."
 
 
-def build_models(device):
+def csrc_digest() -> str:
+    """Content hash of the kernel sources: profiles record it, so a profile taken before the last kernel change is detectable."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "v3d_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_models(device, width=320, vae_ch=128, steps=STEPS, cfg=CFG, frames=T_FRAMES):
     from v3d_amd import synth
     from v3d_amd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
     from v3d_amd.sgm.modules.diffusionmodules.denoiser import Denoiser
@@ -47,30 +71,30 @@ def build_models(device):
     from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
     with torch.device(device):
-        unet = VideoUNet(**synth.unet_config(320)).eval()
-        dec = VideoDecoder(**synth.decoder_config(128)).eval()
+        unet = VideoUNet(**synth.unet_config(width)).eval()
+        dec = VideoDecoder(**synth.decoder_config(vae_ch)).eval()
     synth.init_module_fast(unet, seed=1)
     synth.init_module_fast(dec, seed=2)
     sampler = EulerEDMSampler(
         discretization_config={"target": P + "discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
-        num_steps=STEPS,
-        guider_config={"target": P + "guiders.LinearPredictionGuider", "params": {"max_scale": CFG, "min_scale": CFG, "num_frames": T_FRAMES}},
+        num_steps=steps,
+        guider_config={"target": P + "guiders.LinearPredictionGuider", "params": {"max_scale": cfg, "min_scale": cfg, "num_frames": frames}},
         device=device)
     denoiser = Denoiser({"target": P + "denoiser_scaling.VScalingWithEDMcNoise"})
     return unet, OpenAIWrapper(unet), dec, sampler, denoiser
 
 
-def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False):
+def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False, frames=T_FRAMES):
     """One sample = 25 guided network evaluations + the 18-frame decode.  With `graph` the network evaluation and the
     decode are captured once (first call) into HIP graphs and replayed (v3d_amd/engine/graph.py)."""
     from v3d_amd.engine.graph import graphed
-    extra = {"image_only_indicator": torch.zeros(2, T_FRAMES, device=device), "num_video_frames": T_FRAMES}
+    extra = {"image_only_indicator": torch.zeros(2, frames, device=device), "num_video_frames": frames}
 
     def den(inp, sigma, cc):
         return denoiser(wrapped, inp, sigma, cc, **extra)
 
     def decode(z):
-        return dec(z, timesteps=T_FRAMES)
+        return dec(z, timesteps=frames)
 
     den_g = graphed(den, enabled=bool(graph))
     dec_g = graphed(decode, enabled=bool(graph))
@@ -83,106 +107,254 @@ def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False
     return step
 
 
-def measure_gemm_roofline(step):
-    """One extra instrumented sample: HIP events around every v3d_gemm / v3d_ff_fused launch on the launch stream."""
+def make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise, c, uc):
+    """One sample with its frames sharded over the ranks for the whole path (v3d_amd/dist.py::sharded_sample): returns the gathered
+    [18, 3, 512, 512] frames on every rank."""
+    from v3d_amd.dist import sharded_sample
+
+    def decode(z):
+        return dec(z * (1.0 / 0.18215), timesteps=shard.T_local)
+
+    def step():
+        return sharded_sample(shard, sampler, denoiser, wrapped, decode, noise.clone(), c, uc, B=1)
+
+    return step
+
+
+# ---- live per-launch timing of one instrumented sample --------------------------------------------------------------------------
+class _Timed:
+    """Wraps the primitive ops of the backend with HIP events on the launch stream and algorithmic flop / byte counts."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.rec = []            # (family, e0, e1, flops, bytes)
+        self.saved = {}
+
+    def _wrap(self, name, meter):
+        orig = getattr(self.ops, name)
+        self.saved[name] = orig
+
+        def timed(*a, **k):
+            fam, flops, by = meter(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            self.rec.append((fam, e0, e1, flops, by))
+            return r
+
+        setattr(self.ops, name, timed)
+
+    def __enter__(self):
+        def m_gemm(g):
+            taps = {0: 1, 1: 9, 2: 3}[g.mode]
+            nout = g.N // 2 if g.geglu else g.N
+            # algorithmic bytes of the launch: activation rows once + packed weights once + output (+ residuals) once
+            by = (g.A.shape[-2] * g.K * 2 + taps * g.N * g.K * 2) * g.batch + g.M * nout * g.out.element_size() * g.batch
+            by += sum(g.M * nout * 2 for r in (g.res1, g.res2) if r is not None)
+            fam = {0: "gemm_linear_geglu" if g.geglu else ("gemm_batched" if g.batch > 1 else "gemm_linear"), 1: "gemm_conv3x3", 2: "gemm_convt3"}[g.mode]
+            return fam, 2.0 * g.M * g.N * g.K * taps * g.batch, by
+
+        def m_ff(x, w1p, b1, w2p, b2, out, **kw):
+            # both GEMMs of the block in one launch: 2 M C (2 hidden) + 2 M hidden C flops; bytes = x, both weight matrices, the output and
+            # the residuals once (the hidden tensor never exists in memory)
+            M, C, hidden = x.shape[0], x.shape[1], w2p.shape[-1]
+            by = 2 * M * C * 2 + 3 * C * hidden * 2 + sum(M * C * 2 for k in ("res1", "res2") if kw.get(k) is not None)
+            return "gemm_ff_fused", 6.0 * M * C * hidden, by
+
+        def m_attn(q, k, vT, out, n_img, S, heads, scale):
+            return "attn_spatial", 4.0 * n_img * heads * S * S * 64, 4 * n_img * S * heads * 64 * 2
+
+        def m_tattn(q, k, v, out, heads, scale):
+            B, Tq, S, C = q.shape
+            Tk = k.shape[1]
+            return "attn_temporal", 4.0 * B * S * heads * Tq * Tk * 64, (2 * B * Tq * S * C + 2 * B * Tk * S * C) * 2
+
+        def m_gns(x1, x2, stats, n_img, S, groups, ips):
+            C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+            return "gn_stats", 0.0, n_img * S * C * 2
+
+        def m_gna(x1, x2, stats, gamma, beta, out, n_img, S, *a):
+            C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+            return "gn_apply", 0.0, 2 * n_img * S * C * 2
+
+        def m_ln(x, gamma, beta, out, eps, add=None, add_rpg=0, add_ld=0, xsum_out=None):
+            return "layernorm", 0.0, (3 if xsum_out is not None else 2) * x.numel() * 2
+
+        self._wrap("gemm", m_gemm)
+        if hasattr(self.ops, "ff_fused"):
+            self._wrap("ff_fused", m_ff)
+        self._wrap("attn_spatial", m_attn)
+        self._wrap("attn_temporal", m_tattn)
+        self._wrap("groupnorm_stats", m_gns)
+        self._wrap("groupnorm_apply", m_gna)
+        self._wrap("layernorm", m_ln)
+        if hasattr(self.ops, "attn_vae"):
+            self._wrap("attn_vae", lambda q, k, v, out, n_img, S, C, scale: ("attn_vae_d512", 4.0 * n_img * S * S * C, 4 * n_img * S * C * 2))
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.saved:
+            self.ops.__dict__.pop(k, None)     # the originals are class attributes: dropping the instance override restores them
+
+    def families(self):
+        fam = {}
+        for f, e0, e1, fl, by in self.rec:
+            a = fam.setdefault(f, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += fl
+            a[2] += by
+            a[3] += 1
+        return fam
+
+
+def measure_rooflines(step):
+    """One extra instrumented sample: HIP events around every timed op launch on the launch stream."""
     from v3d_amd.ops import get_ops
-    ops = get_ops()
-    orig = ops.gemm
-    rec = []
-
-    def timed(g):
-        taps = {0: 1, 1: 9, 2: 3}[g.mode]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig(g)
-        e1.record()
-        # algorithmic bytes of the launch: activation rows once + packed weights once + output (+ residuals) once
-        nout = g.N // 2 if g.geglu else g.N
-        by = (g.A.shape[0] * g.K * 2 + taps * g.N * g.K * 2) * g.batch + g.M * nout * g.out.element_size() * g.batch
-        by += sum(g.M * nout * 2 for r in (g.res1, g.res2) if r is not None)
-        rec.append((e0, e1, 2.0 * g.M * g.N * g.K * taps * g.batch, by))
-
-    orig_ff = ops.ff_fused
-
-    def timed_ff(x, w1p, b1, w2p, b2, out, **kw):
-        # the fused feed-forward is both GEMMs of the block in one launch: 2 M C (2 hidden) + 2 M hidden C flops; algorithmic bytes =
-        # x, both weight matrices, the output and the residuals once (the hidden tensor never exists in memory)
-        M, C, hidden = x.shape[0], x.shape[1], w2p.shape[-1]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig_ff(x, w1p, b1, w2p, b2, out, **kw)
-        e1.record()
-        by = 2 * M * C * 2 + 3 * C * hidden * 2 + sum(M * C * 2 for k in ("res1", "res2") if kw.get(k) is not None)
-        rec.append((e0, e1, 6.0 * M * C * hidden, by))
-        return r
-
-    ops.gemm = timed
-    ops.ff_fused = timed_ff
-    try:
+    with _Timed(get_ops()) as t:
         step()
         torch.cuda.synchronize()
-    finally:
-        ops.gemm = orig
-        ops.ff_fused = orig_ff
-    tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
-    flops = sum(f for _, _, f, _ in rec)
-    alg_bytes = sum(b for _, _, _, b in rec)
-    n = len(rec)
+        fam = t.families()
+    per = []
+    for f, (ms, fl, by, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+        mfma = fl / max(by, 1) > PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9) and fl > 0     # above the ridge -> MFMA-bound
+        if f.startswith("attn_spatial") or f.startswith("attn_vae"):
+            mfma = True                                                                        # (QK^T / PV re-read K,V from L2, never HBM-bound)
+        ach = fl / (ms * 1e-3) / 1e12 if mfma else by / (ms * 1e-3) / 1e9
+        per.append({"kernel": f, "bound": "mfma" if mfma else "hbm", "ms_per_sample": round(ms, 2), "launches": n,
+                    "achieved": round(ach, 1), "unit": "TFLOP/s" if mfma else "GB/s",
+                    "frac": round(ach / (PEAK_BF16_TFLOPS if mfma else PEAK_HBM_GBPS), 4)})
+    gem = {k: v for k, v in fam.items() if k.startswith("gemm_")}
+    tot_ms = sum(v[0] for v in gem.values())
+    flops = sum(v[1] for v in gem.values())
+    alg_bytes = sum(v[2] for v in gem.values())
+    n = sum(v[3] for v in gem.values())
     achieved = flops / (tot_ms * 1e-3) / 1e12
-    # HBM-side bytes per launch from the committed rocprofv3 PMC passes of the same workload (FETCH_SIZE / WRITE_SIZE in
-    # separate runs, calibrated on a copy of known size as MI355X_MICROARCH.md prescribes; tools/pmc_eval.py + pmc_traffic.py)
-    traffic = None
+    traffic, tinfo = None, {"file": "profiles/" + PMC_PROFILE, "found": False}
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01m_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
         fams = [v for k, v in pmc["families"].items() if k.startswith("gemm_")]
         traffic = round(sum(v["read_GB_per_eval"] + v["write_GB_per_eval"] for v in fams) * 1e9 / sum(v["launches_per_eval"] for v in fams))
+        tinfo = {"file": "profiles/" + PMC_PROFILE, "found": True, "csrc_sha256_16": pmc.get("csrc_sha256_16"), "taken": pmc.get("taken"),
+                 "kernels_changed_since": pmc.get("csrc_sha256_16") != csrc_digest()}
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3<192x320 | 256x256> + gemm_kernel_v2<128x128 ...> (conv3x3 / convt3 / linear / GEGLU) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards)",
+    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3 / v2 (conv3x3 / convt3 / linear / GEGLU launches) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC, profiles/r01m_pmc_traffic.txt)",
-            "algorithmic_bytes_per_launch": round(alg_bytes / n), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / n, 2),
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC passes)", "traffic_profile": tinfo,
+            "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2),
             "algorithmic_tflop_per_sample": round(flops / 1e12, 2), "gemm_ms_per_sample": round(tot_ms, 2),
-            "measured_on": "one extra instrumented sample after the timed region (HIP events per launch)"}
+            "timed_ms_per_sample_all_families": round(sum(v[0] for v in fam.values()), 2),
+            "measured_on": "one extra instrumented sample after the timed region (HIP events per launch, csrc " + csrc_digest() + ")",
+            "per_kernel": per}
 
 
-def cpu_baseline(unet, dec, budget_s=40.0):
-    """fp32 CPU oracle on a bounded sample: one U-Net evaluation on 4 of the 36 images (cfg 2 x 2 frames, 64x64 latents,
-    full width) + decode of 2 frames; extrapolated linearly to 25 x 36-image evaluations + 18 decoded frames."""
+def cpu_baseline(unet, dec):
+    """fp32 CPU oracle on a bounded sample: a warm-up evaluation, then TWO timed U-Net evaluations on 6 of the 36 images (one cfg half,
+    T = 6 frames, 64x64 latents, full width) + decode of 2 frames; extrapolated linearly to 25 x 36-image evaluations + 18 decoded
+    frames.  The HIP engine is checked against the oracle on the same inputs."""
     from oracle import sgm_oracle as O
     from v3d_amd import synth
     torch.set_grad_enabled(False)
     cores = torch.get_num_threads()
-    Tb = 2
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    cfg = synth.unet_config(320)
     g = torch.Generator().manual_seed(0)
-    n = 2 * Tb
-    x8 = torch.randn(n, 8, LAT, LAT, generator=g)
-    ts = torch.randn(n, generator=g)
-    ctx = torch.randn(n, 1, 1024, generator=g)
-    y = torch.randn(n, 768, generator=g)
-    t0 = time.time()
-    ref = O.unet_forward(sd, synth.unet_config(320), x8, ts, ctx, y, Tb, torch.zeros(2, Tb))
-    t_unet = time.time() - t0
+
+    def inputs(n):
+        return (torch.randn(n, 8, LAT, LAT, generator=g), torch.randn(n, generator=g), torch.randn(n, 1, 1024, generator=g), torch.randn(n, 768, generator=g))
+
+    xw, tw, cw, yw = inputs(2)
+    O.unet_forward(sd, cfg, xw, tw, cw, yw, 2, torch.zeros(1, 2))                     # warm-up (thread pool, oneDNN primitives, first touch)
+    Tb = 6
+    x8, ts, ctx, y = inputs(Tb)
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        ref = O.unet_forward(sd, cfg, x8, ts, ctx, y, Tb, torch.zeros(1, Tb))
+        times.append(time.time() - t0)
+    t_unet = sum(times) / len(times)
     del sd
     # full-width parity spot check on the same inputs: HIP engine (bf16) vs the fp32 oracle
     dev = next(unet.parameters()).device
-    got = unet(x8.to(dev), ts.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=Tb, image_only_indicator=torch.zeros(2, Tb, device=dev))
+    got = unet(x8.to(dev), ts.to(dev), context=ctx.to(dev), y=y.to(dev), num_video_frames=Tb, image_only_indicator=torch.zeros(1, Tb, device=dev))
     cos_unet = torch.nn.functional.cosine_similarity(got.float().cpu().flatten(), ref.flatten(), dim=0).item()
     rel_unet = ((got.float().cpu() - ref).abs().max() / ref.abs().max()).item()
     dsd = {k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
-    z = torch.randn(Tb, 4, LAT, LAT, generator=g)
+    Td = 2
+    z = torch.randn(Td, 4, LAT, LAT, generator=g)
     t0 = time.time()
-    dref = O.decoder_forward(dsd, synth.decoder_config(128), z, Tb)
+    dref = O.decoder_forward(dsd, synth.decoder_config(128), z, Td)
     t_vae = time.time() - t0
-    dgot = dec(z.to(dev), timesteps=Tb)
+    dgot = dec(z.to(dev), timesteps=Td)
     cos_vae = torch.nn.functional.cosine_similarity(dgot.float().cpu().flatten(), dref.flatten(), dim=0).item()
-    t_sample = STEPS * t_unet * (2 * T_FRAMES / n) + t_vae * (T_FRAMES / Tb)
+    t_sample = STEPS * t_unet * (2 * T_FRAMES / Tb) + t_vae * (T_FRAMES / Td)
     return {"value": round(T_FRAMES / t_sample, 6), "unit": "frames/s", "cores": cores, "kind": "port",
             "parity_full_width": {"unet_eval_cosine": round(cos_unet, 6), "unet_eval_max_rel_err": round(rel_unet, 5),
                                   "vae_decode_cosine": round(cos_vae, 6), "note": "HIP bf16 engine vs fp32 CPU oracle on the timed sample's inputs"},
-            "sample": f"fp32 oracle: 1 U-Net eval on {n}/36 images ({t_unet:.1f} s) + decode of {Tb}/18 frames ({t_vae:.1f} s), "
-                      f"extrapolated to 25 evals x 36 images + 18 frames = {t_sample:.0f} s/sample"}
+            "sample": f"fp32 oracle, {cores} threads: warm-up eval, then 2 timed U-Net evals on {Tb}/36 images at T={Tb} ({times[0]:.1f} s, {times[1]:.1f} s) + decode of {Td}/18 "
+                      f"frames ({t_vae:.1f} s), extrapolated to 25 evals x 36 images + 18 frames = {t_sample:.0f} s/sample"}
+
+
+def parity_rollout(device, lat=32):
+    """SURVEY.md 8d end-to-end bar, measured live on a bounded case: width-64 network, T = 18, 25 EulerEDM steps, cfg 4.5, decode - HIP
+    path vs the fp32 oracle: latent cosine and decoded-frame PSNR (peak = value range of the oracle's frames).  Live at 32x32 latents
+    (-> 256x256 frames; the 25-step oracle rollout at 64x64 takes minutes of CPU time); the 64x64 numbers of the -m gpu test
+    tests/test_headline_parity_gpu.py::test_rollout_25_steps_cosine_and_psnr are attached from profiles/ with their provenance."""
+    from oracle import sgm_oracle as O
+    from v3d_amd import synth
+    from v3d_amd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    from v3d_amd.sgm.modules.diffusionmodules.video_model import VideoUNet
+    from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    unet = VideoUNet(**synth.unet_config(64)).eval()
+    dec = VideoDecoder(**synth.decoder_config(32)).eval()
+    unet.load_state_dict(synth.seeded_state_dict(unet, 1234))
+    dec.load_state_dict(synth.seeded_state_dict(dec, 1235))
+    usd = {k: v.float() for k, v in unet.state_dict().items()}
+    dsd = {k: v.float() for k, v in dec.state_dict().items()}
+    unet, dec = unet.to(device), dec.to(device)
+    sampler, denoiser = build_models_sampler(device)
+    noise, c, uc = synth.synthetic_conditioning(T_FRAMES, lat, lat, seed=23)
+    mv = lambda d: {k: v.to(device) for k, v in d.items()}
+    z = make_step_latents(OpenAIWrapper(unet), sampler, denoiser, noise.clone().to(device), mv(c), mv(uc), device)
+    frames = dec(z * (1.0 / 0.18215), timesteps=T_FRAMES).float().cpu()
+    ioi = torch.zeros(2, T_FRAMES)
+    ucfg, dcfg = synth.unet_config(64), synth.decoder_config(32)
+    t0 = time.time()
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 32))          # small-op workload: more threads make it slower
+    z_ref = O.sample_edm(lambda x8, cn, ctx, vec: O.unet_forward(usd, ucfg, x8, cn, ctx, vec, T_FRAMES, ioi), noise.clone(), c, uc, STEPS, T_FRAMES, CFG, CFG, 700.0)
+    f_ref = O.decode_first_stage(dsd, dcfg, z_ref, 0.18215, T_FRAMES)
+    torch.set_num_threads(nthr)
+    dt = time.time() - t0
+    cos = torch.nn.functional.cosine_similarity(z.double().cpu().flatten(), z_ref.double().flatten(), dim=0).item()
+    mse = ((frames.double() - f_ref.double()) ** 2).mean().item()
+    peak = (f_ref.max() - f_ref.min()).item()
+    out = {"config": f"width 64, T=18, {lat}x{lat} latent, 25 EulerEDM steps, cfg 4.5, decode to {8 * lat}x{8 * lat}", "latent_cosine": round(cos, 6),
+           "frames_psnr_db": round(10.0 * math.log10(peak * peak / mse), 2) if mse > 0 else None, "oracle_seconds": round(dt, 1)}
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_parity.json")))
+        r = rec["rollout_25_steps_width64"]
+        out["recorded_64x64"] = {"latent_cosine": r["latent_cosine"], "frames_psnr_db": r["frames_psnr_db"], "decoder_only_psnr_db": r.get("decoder_only_psnr_db"),
+                                 "source": "profiles/r02_parity.json (written by tests/test_headline_parity_gpu.py on the GPU box)",
+                                 "headline_unet_eval": rec.get("headline_unet_eval")}
+    except Exception:
+        pass
+    return out
+
+
+def build_models_sampler(device):
+    from v3d_amd.sgm.modules.diffusionmodules.denoiser import Denoiser
+    from v3d_amd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    sampler = EulerEDMSampler(
+        discretization_config={"target": P + "discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}}, num_steps=STEPS,
+        guider_config={"target": P + "guiders.LinearPredictionGuider", "params": {"max_scale": CFG, "min_scale": CFG, "num_frames": T_FRAMES}}, device=device)
+    return sampler, Denoiser({"target": P + "denoiser_scaling.VScalingWithEDMcNoise"})
+
+
+def make_step_latents(wrapped, sampler, denoiser, noise, c, uc, device):
+    extra = {"image_only_indicator": torch.zeros(2, T_FRAMES, device=device), "num_video_frames": T_FRAMES}
+    return sampler(lambda i, s, cc: denoiser(wrapped, i, s, cc, **extra), noise, cond=c, uc=uc)
 
 
 def main():
@@ -190,8 +362,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shard", choices=["replica", "frames"], default="replica",
+                    help="multi-GPU mode: independent samples per rank (weak scaling, default) or ONE sample with its frames sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-rollout", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay captured HIP graphs of the network evaluation / decode instead of launching from Python "
                          "(measured 9.59 vs 9.62 frames/s: ROCm 7.2 graph replay does not close the launch gaps, so it is off by default)")
@@ -213,46 +388,80 @@ def main():
     from v3d_amd.ops import get_ops
     assert get_ops().name == "hip"
     unet, wrapped, dec, sampler, denoiser = build_models(device)
-    # every rank generates its own sample (different seed per rank): independent objects, no data-path collective
-    noise, c, uc = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23 + rank, device=device)
-    step = make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=args.graph)
+    shard_mode = args.shard == "frames" and world > 1
+    # replica mode: every rank generates its own sample (different seed per rank); frame-shard mode: ONE sample, same inputs everywhere
+    noise, c, uc = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23 + (0 if shard_mode else rank), device=device)
+    shard = None
+    if world > 1:
+        from v3d_amd.dist import FrameShard
+        shard = FrameShard(T_FRAMES)
+    if shard_mode:
+        step = make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise, c, uc)
+    else:
+        step = make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=args.graph)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed(fn, warmup, steps):
+        for _ in range(warmup):
+            out = fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return out, dt
+
+    out, dt = timed(step, args.warmup, args.steps)
     assert out.shape == (T_FRAMES, 3, LAT * 8, LAT * 8) and torch.isfinite(out).all()
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     result = None
+    samples = args.steps * (1 if shard_mode else world)
     if rank == 0:
-        frames = world * args.steps * T_FRAMES
+        frames = samples * T_FRAMES
         sample_tflop = STEPS * F_UNET_TFLOP + T_FRAMES * F_VAE_TFLOP_PER_FRAME
+        par = f"frame-shard {shard.describe()}" if shard_mode else f"replica x{world}"
         result = {
             "metric": "multi-view frames/sec, V3D_512 18-frame 25-step EDM", "value": round(frames / dt, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: V3D_512 random-init SVD-XT weights, 1x18x4x64x64 latent, 25 EulerEDM steps, "
-                                   "cfg 4.5 (LinearPredictionGuider), 18-frame VideoDecoder decode to 512x512, one sample per GPU",
-                       "frames": T_FRAMES, "edm_steps": STEPS, "latent": [T_FRAMES, 4, LAT, LAT], "parallelism": f"replica x{world}"},
-            "achieved_tflops_reference_graph": round(world * args.steps * sample_tflop / dt, 1),
-            "frac_of_bf16_peak_reference_graph": round(args.steps * sample_tflop / dt / PEAK_BF16_TFLOPS, 4),
+                                   "cfg 4.5 (LinearPredictionGuider), 18-frame VideoDecoder decode to 512x512, "
+                                   + ("ONE sample, frames sharded over the GPUs (configs[2]/[3])" if shard_mode else "one sample per GPU"),
+                       "frames": T_FRAMES, "edm_steps": STEPS, "latent": [T_FRAMES, 4, LAT, LAT], "parallelism": par},
+            "achieved_tflops_reference_graph": round(samples * sample_tflop / dt, 1),
+            "frac_of_bf16_peak_reference_graph": round(samples * sample_tflop / dt / PEAK_BF16_TFLOPS / world, 4),
         }
+    # ---- N > 1, replica mode: the frame-sharded (latency) mode of the same job, measured after the timed region ----
+    if world > 1 and not shard_mode:
+        fs = None
+        try:
+            n_fs = max(1, min(args.steps, 3))
+            noise0, c0, uc0 = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23, device=device)
+            sstep = make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise0, c0, uc0)
+            sent0 = shard.bytes_sent
+            fout, fdt = timed(sstep, 1, n_fs)
+            ok = bool(fout.shape == (T_FRAMES, 3, LAT * 8, LAT * 8) and torch.isfinite(fout).all())
+            fs = {"value": round(n_fs * T_FRAMES / fdt, 4), "unit": "frames/s", "ms_per_sample": round(fdt / n_fs * 1e3, 2), "steps": n_fs, "warmup": 1,
+                  "scaling": "strong", "parallelism": f"frame-shard {shard.describe()}", "finite": ok,
+                  "sent_MB_per_sample_rank0": round((shard.bytes_sent - sent0) / (n_fs + 1) / 1e6, 1),
+                  "note": "ONE sample, frames sharded over the ranks for all 25 steps + decode (v3d_amd/dist.py::sharded_sample); not part of `value`"}
+        except Exception as e:   # never lose the replica number to the secondary measurement
+            fs = {"value": None, "error": f"{type(e).__name__}: {e}"[:400]}
+        if rank == 0:
+            result["frame_shard"] = fs
     if rank == 0 and not args.no_roofline:
-        # per-launch HIP events need the launches to come from Python: the instrumented sample runs un-captured
-        result["roofline"] = measure_gemm_roofline(make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False))
+        # per-launch HIP events need the launches to come from Python: the instrumented sample runs un-captured (and un-sharded)
+        noise0, c0, uc0 = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23, device=device)
+        result["roofline"] = measure_rooflines(make_step(wrapped, dec, sampler, denoiser, noise0, c0, uc0, device, graph=False))
         result["config"]["hip_graph"] = bool(args.graph)
     if world > 1:
         dist.barrier()
@@ -261,6 +470,12 @@ def main():
             result["cpu_baseline"] = cpu_baseline(unet, dec)
         except Exception as e:  # the baseline is informational; never lose the GPU number to a host-side failure
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
+        if not args.no_parity_rollout:
+            try:
+                del unet, wrapped, dec
+                result["cpu_baseline"]["parity_rollout"] = parity_rollout(device)
+            except Exception as e:
+                result["cpu_baseline"]["parity_rollout"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

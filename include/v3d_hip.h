@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 2
+#define V3D_ABI_VERSION 3
 #define V3D_GN_SLOTS 32
 
 typedef void* v3d_stream_t; /* hipStream_t */
@@ -62,7 +62,10 @@ int v3d_device_info(int32_t* out4);
  * mode V3D_GEMM_CONVT3 : 3 taps along the frame axis; rows are (frame, s) with S rows per frame; tap dt reads
  *      row m + (dt-1)*S when tmin <= (frame % T) + dt - 1 <= tmax, else zero.
  *      replaces Conv3d (3,1,1) pad (1,0,0) (video_model.py:42-55 via openaimodel.py:267-313; temporal_ae.py:32-44).
- *      With frame sharding the caller points A at a buffer carrying +-1 halo frames and widens [tmin,tmax].
+ *      With frame sharding the caller points A at a buffer carrying +-1 halo frames and widens [tmin,tmax]: either one sample
+ *      with its halo frames in line (a_row0 = S, frames -1 .. T), or (ABI 3) the split-halo layout `halo_rows` = B*S > 0 for B
+ *      samples in one launch: rows [a_row0 - B*S, a_row0) hold frame -1 of sample 0 .. B-1 (received from the previous rank),
+ *      rows [a_row0, a_row0 + M) the B*T local frames, rows [a_row0 + M, a_row0 + M + B*S) frame T of every sample.
  * ---------------------------------------------------------------------------------------------- */
 enum { V3D_GEMM_LINEAR = 0, V3D_GEMM_CONV3X3 = 1, V3D_GEMM_CONVT3 = 2 };
 
@@ -90,6 +93,14 @@ typedef struct v3d_gemm_args {
     int32_t pad_mode;                         /* CONV3X3 (ABI 2): 0 = one zero pixel on every side (Conv2d padding=1); 1 = right/bottom only,
                                                  F.pad(x,(0,1,0,1)) + padding=0: the VAE encoder's Downsample (diffusionmodules/model.py:74-91) */
     int64_t sA, sW, sO;                       /* element strides between batches (A, W, out) */
+    int64_t halo_rows;                        /* CONVT3 (ABI 3): 0 = dense frames; B*S = split-halo layout, see above */
+    /* (ABI 3) GroupNorm statistics of the OUTPUT, accumulated by the epilogue so that the next GroupNorm needs no statistics pass:
+     * gn_stats[(m / gn_rps)][slot][n / gn_cpg][2] += (sum, sumsq) of the bf16-rounded out[m][n]  (layout of v3d_groupnorm_stats,
+     * V3D_GN_SLOTS slots, caller zeroes).  NULL = off.  Needs bf16 out, !geglu, N % gn_cpg == 0, 32 groups (N / gn_cpg == 32). */
+    float* gn_stats;
+    int64_t gn_rps;                           /* rows per statistics group (imgs_per_stat * S) */
+    int32_t gn_cpg;                           /* channels per group */
+    int32_t reserved0;
 } v3d_gemm_args;
 
 int v3d_gemm(const v3d_gemm_args* args, v3d_stream_t stream);

@@ -58,8 +58,13 @@ class EmulOps(OpsBase):
                 tt = t + dt - 1
                 valid = (tt >= g.tmin) & (tt <= g.tmax)
                 src = m + g.a_row0 + (dt - 1) * g.S
+                if g.halo_rows:
+                    frame = m // g.S
+                    hoff = (frame // g.T) * g.S + (m - frame * g.S)
+                    src = torch.where(tt < 0, g.a_row0 - g.halo_rows + hoff, src)
+                    src = torch.where(tt >= g.T, g.a_row0 + M + hoff, src)
                 src = torch.where(valid, src, torch.zeros_like(src))
-                rows = Af[src] * valid[:, None].float()
+                rows = torch.where(valid[:, None], Af[src], torch.zeros((), dtype=Af.dtype, device=Af.device))   # (masked rows may be uninitialised halo slabs)
                 acc += rows @ w[dt].t()
             return acc
         raise ValueError(g.mode)
@@ -91,6 +96,11 @@ class EmulOps(OpsBase):
             if g.res2 is not None:
                 o = o + c2 * g.res2[:M].float()
             out[:M].copy_(o.to(out.dtype))
+            if g.gn_stats is not None:
+                # GroupNorm partial sums of the stored (rounded) output, layout of groupnorm_stats (slot 0 only in the emulator)
+                v = out[:M].float().reshape(M // g.gn_rps, g.gn_rps, N // g.gn_cpg, g.gn_cpg)
+                g.gn_stats[:, 0, :, 0] += v.sum(dim=(1, 3))
+                g.gn_stats[:, 0, :, 1] += (v * v).sum(dim=(1, 3))
 
     # ---- norms ------------------------------------------------------------------------------------
     @staticmethod
@@ -327,7 +337,7 @@ class EmulOps(OpsBase):
             tt = t + dt - 1
             valid = ((tt >= tmin) & (tt <= tmax)).float()
             src = (f + f0 + dt - 1).clamp(0, nfr - 1)
-            xs = xf[src] * valid[:, None, None]                        # [f, s, ci]
+            xs = torch.where(valid[:, None, None] > 0, xf[src], torch.zeros((), dtype=xf.dtype, device=xf.device))   # [f, s, ci]
             out += torch.einsum("fsi,oi->fos", xs, w[:, :, dt].float())
         return out + b.float()[None, :, None]
 

@@ -27,7 +27,7 @@ def hip_ops():
 
 
 def rel_cos(a: torch.Tensor, b: torch.Tensor):
-    a, b = a.float().flatten().cpu(), b.float().flatten().cpu()
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()      # (fp32 dot products of 10^7 elements drift past 1.0)
     rel = ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
     cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
     return rel, cos

@@ -54,7 +54,22 @@ def _worker(rank, world, port, q):
             fr_loc = run_decoder(dec.packed(), sh.take_frames(z, 1), sh.T_local, shard=sh)
             fr = sh.gather_frames_out(fr_loc.contiguous(), 1)
             err_dec = ((fr - golden["dec_out"]).abs().max() / golden["dec_out"].abs().max()).item()
-        q.put((rank, sh.T_local, err_unet, err_dec))
+            # the whole path sharded: sampler loop on local frames (per-frame guidance scale by GLOBAL frame id), local decode,
+            # gather of the decoded frames only - against the reference sampler fixture and the unsharded decode of it
+            from tiny import build_denoiser, build_sampler
+            from v3d_amd.dist import sharded_sample
+            from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+            noise, c, uc, *_ = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+            sampler, den, wr = build_sampler(T), build_denoiser(), OpenAIWrapper(net)
+            zs = sharded_sample(sh, sampler, den, wr, lambda zz: zz, noise.clone(), c, uc, B=1)
+            err_samp = ((zs - golden["sample_z"]).abs().max() / golden["sample_z"].abs().max()).item()
+            zin = torch.randn(T, 4, 8, 8, generator=torch.Generator().manual_seed(9))
+            fs = sharded_sample(sh, build_sampler(T, steps=1), den, wr, lambda zz: dec(zin[sh.t0:sh.t0 + sh.T_local] + 0 * zz[:, :, :8, :8], timesteps=sh.T_local),
+                                noise.clone(), c, uc, B=1)
+            err_samp = max(err_samp, ((fs - dec(zin, timesteps=T)).abs().max() / fs.abs().max()).item())
+            assert sampler.guider.num_frames == T and sampler.guider.scale.shape == (1, T)      # the caller's sampler is untouched
+            sent = sh.bytes_sent
+        q.put((rank, sh.T_local, err_unet, err_dec, err_samp, sent))
     except Exception as e:  # report instead of leaving the parent waiting on the queue
         import traceback
         q.put((rank, -1, traceback.format_exc(), str(e)))
@@ -78,6 +93,8 @@ def test_two_rank_uneven_frame_shard_matches_unsharded():
         assert r[1] >= 0, f"rank {r[0]} failed:\n{r[2]}"
     res.sort()
     assert [r[1] for r in res] == [2, 1]          # uneven 2 + 1 split
-    for rank, _, e_unet, e_dec in res:
+    for rank, _, e_unet, e_dec, e_samp, sent in res:
         assert e_unet <= 5e-5, f"rank {rank}: sharded U-Net differs from the unsharded reference fixture: {e_unet}"
         assert e_dec <= 5e-5, f"rank {rank}: sharded VAE decode differs from the unsharded reference fixture: {e_dec}"
+        assert e_samp <= 5e-5, f"rank {rank}: sharded sampler loop / decode differs from the unsharded result: {e_samp}"
+        assert sent > 0

@@ -57,4 +57,13 @@ for f, (rd, wr, n) in sorted(fam.items(), key=lambda kv: -(kv[1][0] * fr + kv[1]
     out["families"][f] = {"launches_per_eval": n / n_eval, "read_GB_per_eval": r_gb, "write_GB_per_eval": w_gb}
     print(f"{f:22s} {n / n_eval:13.0f} {r_gb:13.2f} {w_gb:14.2f} {r_gb + w_gb:12.2f}")
 if len(sys.argv) > 4:
+    # stamp the profile with the kernel sources it was taken on (bench.py / tests/test_bench_contract.py detect a stale profile)
+    import datetime, glob, hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "v3d_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    out["csrc_sha256_16"] = h.hexdigest()[:16]
+    out["taken"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")
     json.dump(out, open(sys.argv[4], "w"), indent=1)

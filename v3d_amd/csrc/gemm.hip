@@ -55,6 +55,7 @@ struct GP {
     int pad_lo;          // zero pixels before the first row / column (1, or 0 for the asymmetric right/bottom padding)
     int T, tmin, tmax;
     long long S;
+    long long halo_rows; // CONVT3 split-halo layout (0 = dense)
     long long sA, sW, sO;
     int mt, nt;  // tile counts
     int split_n;         // > 1: split-K launch: blockIdx.y = split index = output slab (out = fp32 workspace [split][M][N], plain stores)
@@ -111,6 +112,7 @@ struct RowInfo<V3D_GEMM_CONV3X3> {
 template <>
 struct RowInfo<V3D_GEMM_CONVT3> {
     long long m_;
+    long long hoff_;   // split-halo layout only: b * S + s, the row of this (sample, position) inside a halo slab
     int t_;
     bool ok;
     __device__ void init(const GP& p, long long m) {
@@ -118,10 +120,18 @@ struct RowInfo<V3D_GEMM_CONVT3> {
         m_ = m;
         long long frame = m / p.S;
         t_ = (int)(frame % p.T);
+        hoff_ = (frame / p.T) * p.S + (m - frame * p.S);
     }
     __device__ bool tap(const GP& p, int t, long long& s) const {
         int tt = t_ + t - 1;
         s = m_ + (long long)(t - 1) * p.S;
+        // frame sharding (halo_rows = B * S): frame -1 of every sample lives in the slab in FRONT of the local frames, frame T in
+        // the slab BEHIND them, so the +-1 frames of a sample never alias the neighbouring sample's frames and all B samples of
+        // a rank go through one launch
+        if (p.halo_rows > 0) {
+            if (tt < 0) s = hoff_ - p.halo_rows;
+            else if (tt >= p.T) s = p.M + hoff_;
+        }
         return ok && tt >= p.tmin && tt <= p.tmax;
     }
 };
@@ -1218,6 +1228,7 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     p.upshift = 0;
     p.pad_lo = 1;
     p.T = a->T; p.tmin = a->tmin; p.tmax = a->tmax; p.S = a->S;
+    p.halo_rows = a->mode == V3D_GEMM_CONVT3 ? a->halo_rows : 0;
     p.sA = a->sA; p.sW = a->sW; p.sO = a->sO;
     p.mt = p.nt = 0;
     p.split_n = 1;
@@ -1239,6 +1250,12 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
             return dispatch<V3D_GEMM_CONV3X3, false>(p, a->batch, st);
         case V3D_GEMM_CONVT3:
             V3D_REQUIRE(a->T > 0 && a->S > 0, "v3d_gemm: convt3 needs T,S");
+            V3D_REQUIRE(a->halo_rows >= 0, "v3d_gemm: halo_rows must be >= 0");
+            if (a->halo_rows > 0) {
+                V3D_REQUIRE(a->M % ((long long)a->T * a->S) == 0 && a->halo_rows == a->M / a->T, "v3d_gemm: split-halo layout needs M = B*T*S and halo_rows = B*S");
+                V3D_REQUIRE(a->a_row0 >= a->halo_rows && a->a_rows >= a->a_row0 + a->M + a->halo_rows, "v3d_gemm: split-halo layout: A must hold halo_rows rows on either side of the M local rows");
+                V3D_REQUIRE(a->tmin >= -1 && a->tmax <= a->T, "v3d_gemm: split-halo layout carries one halo frame per side");
+            }
             return dispatch<V3D_GEMM_CONVT3, false>(p, a->batch, st);
         default:
             v3d_set_error("v3d_gemm: unknown mode %d", a->mode);

@@ -72,19 +72,22 @@ def res_temporal(env: Env, g: Geo, p: ResPack, xs: torch.Tensor, *, coef=None, c
     S, T = g.S, g.T
     sh = env.shard
     gn_kw = dict(imgs_per_stat=T)
+    C = xs.shape[-1]
     if sh is not None:
         gn_kw.update(stats_hook=sh.allreduce_stats, count_imgs=sh.T_global)
+    # frame-sharded: GroupNorm writes the local frames straight into the middle of the split-halo buffer the 3-tap GEMM reads
+    buf, mid = sh.halo_buffer(g.B, S, C, ops.act_dtype, xs.device) if sh is not None else (None, None)
     ga, be, eps = p.t_gn1
-    h = ops.groupnorm(xs, None, ga, be, g.n, S, eps=eps, silu=True, **gn_kw)
+    h = ops.groupnorm(xs, None, ga, be, g.n, S, eps=eps, silu=True, out=mid, **gn_kw)
     epi = {}
     if p.t_emb_off >= 0:
         epi = dict(add=env.emb_all[:, p.t_emb_off:], add_rpg=S, add_ld=env.emb_all.stride(0))
     if sh is None:
         h = ops.convt3(h, p.t_w1, p.t_b1, T, S, **epi)
     else:
-        h = sh.convt3(ops, h, p.t_w1, p.t_b1, g, **epi)
+        h = sh.convt3(ops, buf, p.t_w1, p.t_b1, g, **epi)
     ga, be, eps = p.t_gn2
-    h = ops.groupnorm(h, None, ga, be, g.n, S, eps=eps, silu=True, **gn_kw)
+    h = ops.groupnorm(h, None, ga, be, g.n, S, eps=eps, silu=True, out=mid, **gn_kw)
     epi = dict(res1=xs)
     if coef is not None:
         epi.update(coef=coef, coef_rpg=S)
@@ -92,7 +95,7 @@ def res_temporal(env: Env, g: Geo, p: ResPack, xs: torch.Tensor, *, coef=None, c
         epi.update(c_acc=c_acc, c_res1=1.0)
     if sh is None:
         return ops.convt3(h, p.t_w2, p.t_b2, T, S, **epi)
-    return sh.convt3(ops, h, p.t_w2, p.t_b2, g, **epi)
+    return sh.convt3(ops, buf, p.t_w2, p.t_b2, g, **epi)
 
 
 def unet_resblock(env: Env, g: Geo, p: ResPack, x1, x2=None):
@@ -102,7 +105,7 @@ def unet_resblock(env: Env, g: Geo, p: ResPack, x1, x2=None):
 
 
 def vae_resblock(env: Env, g: Geo, p: ResPack, x):
-    """VideoResBlock of the VAE decoder: alpha * temporal + (1 - alpha) * spatial (temporal_ae.py:79-80 — the
+    """VideoResBlock of the VAE decoder: alpha * temporal + (1 - alpha) * spatial (temporal_ae.py:79-80 - the
     opposite convention), i.e. xs + alpha * (time_stack residual)."""
     xs = res_spatial(env, g, p, x, None)
     return res_temporal(env, g, p, xs, c_acc=p.alpha)

@@ -84,13 +84,18 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     x_t = feed_forward(ops, nin, p.t_ff_in, res1=x_mix)
     ga, be, eps = p.t_norm1
     ops.layernorm(x_t, ga, be, n1, eps)
-    qkv = ops.linear(n1, p.t_wqkv).view(B, T, S, 3 * C)
     ta = ops.empty((B, T, S, C), ops.act_dtype, x.device)
     if sh is None:
+        qkv = ops.linear(n1, p.t_wqkv).view(B, T, S, 3 * C)
         ops.attn_temporal(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], ta, p.heads, 0.125)
     else:
-        kv = sh.allgather_frames(qkv[..., C:])             # [B, T_global, S, 2C]
-        ops.attn_temporal(qkv[..., :C], kv[..., :C], kv[..., C:], ta, p.heads, 0.125)
+        # frame-sharded: to_k | to_v first, their all-gather along frames goes out at once (asynchronously: RCCL's own stream on
+        # the box) and the to_q GEMM runs while it is in flight
+        kv_loc = ops.linear(n1, p.t_wqkv[C:]).view(B, T, S, 2 * C)
+        kv, pending = sh.allgather_frames(kv_loc, async_op=True)              # [B, T_global, S, 2C]
+        q = ops.linear(n1, p.t_wqkv[:C]).view(B, T, S, C)
+        pending.wait()
+        ops.attn_temporal(q, kv[..., :C], kv[..., C:], ta, p.heads, 0.125)
     # temporal attn2: context = frame-0 context of each sample (video_attention.py:249-253) -> per-sample vector
     # (rows n.. of ctx_all hold the frame-0 projections, one per sample)
     x_t = ops.linear(ta.view(n * S, C), p.t_wo[0], p.t_wo[1], res1=x_t, add=ctx[n:, p.t_ctx_off:], add_rpg=S * T,
@@ -129,8 +134,14 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
     n, _, H, W = x.shape
     ops.begin_evaluation(x.device)
     T = int(num_video_frames) if num_video_frames is not None else 1
+    if shard is None:
+        from ..dist import active_shard
+        shard = active_shard()
     if shard is not None:
         T = shard.T_local
+        if context_frame0 is None:
+            context_frame0 = shard.context_frame0
+        assert context_frame0 is not None, "frame-sharded evaluation needs the context of each sample's global frame 0 (FrameShard.activate)"
     assert n % T == 0, f"batch {n} is not a multiple of num_video_frames {T}"
     B = n // T
     dev = x.device
@@ -158,7 +169,10 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
     # merge_strategy="learned_with_images" needs the indicator (AlphaBlender.get_alpha asserts it, util.py:352-354)
     assert not pk.uses_ioi or image_only_indicator is not None, "image_only_indicator is required by merge_strategy='learned_with_images'"
     if pk.uses_ioi and image_only_indicator is not None:
-        ioi = image_only_indicator.reshape(-1).float().contiguous()
+        ioi = image_only_indicator
+        if shard is not None and ioi.numel() == B * shard.T_global:      # full-length indicator: keep this rank's frames
+            ioi = ioi.reshape(B, shard.T_global)[:, shard.t0:shard.t0 + T]
+        ioi = ioi.reshape(-1).float().contiguous()
         assert ioi.numel() == n, f"image_only_indicator has {ioi.numel()} entries for {n} images"
     coefs = ops.blend_coefs(pk.mix_alpha, pk.mix_kind, ioi, n)
     env = Env(ops=ops, emb_all=emb_all, ctx_all=ctx_all, coefs=coefs, shard=shard)

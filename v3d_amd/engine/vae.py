@@ -45,6 +45,9 @@ def run_decoder(pk: VAEPack, z: torch.Tensor, T: int, shard=None) -> torch.Tenso
     ops = get_ops()
     n, _, H, W = z.shape
     ops.begin_evaluation(z.device)
+    if shard is None:
+        from ..dist import active_shard
+        shard = active_shard()
     assert n % T == 0, f"{n} latent frames is not a multiple of timesteps={T}"
     env = Env(ops=ops, shard=shard)
     g = Geo(n=n, B=n // T, T=T, H=H, W=W)

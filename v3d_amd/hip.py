@@ -16,7 +16,7 @@ from .ops import GemmCall, OpsBase
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libv3d_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i64, c_i32, c_f32, c_f64, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_void_p
 
@@ -36,6 +36,8 @@ class _GemmArgs(C.Structure):
         ("S", c_i64),
         ("batch", c_i32), ("pad_mode", c_i32),
         ("sA", c_i64), ("sW", c_i64), ("sO", c_i64),
+        ("halo_rows", c_i64),
+        ("gn_stats", c_vp), ("gn_rps", c_i64), ("gn_cpg", c_i32), ("reserved0", c_i32),
     ]
 
 
@@ -172,6 +174,10 @@ class HipOps(OpsBase):
         a.T, a.tmin, a.tmax, a.S = g.T, g.tmin, g.tmax, g.S
         a.batch = g.batch
         a.pad_mode = g.pad_mode
+        a.halo_rows = g.halo_rows
+        if g.gn_stats is not None:
+            self._req_c(g.gn_stats, f32, "gemm.gn_stats")
+            a.gn_stats, a.gn_rps, a.gn_cpg = g.gn_stats.data_ptr(), g.gn_rps, g.gn_cpg
         if g.batch > 1:
             if g.mode != 0:
                 raise RuntimeError("gemm: batching is only defined for LINEAR mode")

@@ -60,6 +60,10 @@ class GemmCall:
     a_row0: int = 0
     a_rows: int = 0          # 0 -> A.shape[-2]
     batch: int = 1           # batched (LINEAR only): A / W / out may be 3-D [batch, rows, cols]; a 2-D operand is shared
+    halo_rows: int = 0       # CONVT3 split-halo layout (frame sharding): B*S halo rows on either side of the M local rows
+    gn_stats: Optional[torch.Tensor] = None   # fp32 [M / gn_rps, GN_SLOTS, 32, 2]: GroupNorm partial sums of the output (epilogue)
+    gn_rps: int = 0
+    gn_cpg: int = 0
 
 
 class OpsBase:
@@ -116,6 +120,10 @@ class OpsBase:
         arena[1] += (n + 63) // 64 * 64
         return t
 
+    def gn_stats_buffer(self, n_stat, device, groups=32):
+        """Zeroed partial-sum buffer [n_stat, GN_SLOTS, groups, 2] of one GroupNorm (v3d_groupnorm_stats / the gn_stats epilogue)."""
+        return self.zeros_f32_pooled((n_stat, GN_SLOTS, groups, 2), device)
+
     # ---- composite helpers shared by every backend ------------------------------------------------
     def linear(self, x2d, w, bias=None, *, out=None, out_dtype=None, geglu=False, **epi):
         """x2d [M, K] (row-strided ok) @ w[N, K]^T with the fused epilogue of v3d_gemm."""
@@ -141,7 +149,7 @@ class OpsBase:
                            Hout=Hout, Wout=Wout, stride=stride, up=up, pad_mode=pad_mode, **epi))
         return out
 
-    def convt3(self, x, w, bias, T, S, *, tmin=0, tmax=None, a_row0=0, M=None, out=None, out_dtype=None, **epi):
+    def convt3(self, x, w, bias, T, S, *, tmin=0, tmax=None, a_row0=0, M=None, out=None, out_dtype=None, halo_rows=0, **epi):
         """Temporal 3-tap conv over frames: x [(b t) * S (+halo), C], w [3, Cout, Cin]."""
         K = x.shape[-1]
         N = w.shape[-2]
@@ -152,25 +160,27 @@ class OpsBase:
         if out is None:
             out = self.empty((M, N), out_dtype or self.act_dtype, x.device)
         self.gemm(GemmCall(A=x, W=w, out=out, M=M, N=N, K=K, bias=bias, mode=GEMM_CONVT3, T=T, S=S, tmin=tmin,
-                           tmax=tmax, a_row0=a_row0, **epi))
+                           tmax=tmax, a_row0=a_row0, halo_rows=halo_rows, **epi))
         return out
 
     def groupnorm(self, x1, x2, gamma, beta, n_img, S, *, eps, silu, imgs_per_stat=1, groups=32, stats_hook=None,
-                  count_imgs=None):
+                  count_imgs=None, out=None, stats=None):
         """GroupNorm(+SiLU) over channels-last x1 (and optional channel-concatenated x2).
 
         stats_hook(stats) lets the frame-sharded runtime all-reduce (sum, sumsq) between the two kernels;
         count_imgs = number of images (global) contributing to one statistics group.
         """
         C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
-        stats = self.zeros_f32_pooled((n_img // imgs_per_stat, GN_SLOTS, groups, 2), x1.device)
-        self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
+        if stats is None:      # else: the partial sums were accumulated by the epilogue of the GEMM that produced x1 (GemmCall.gn_stats)
+            stats = self.gn_stats_buffer(n_img // imgs_per_stat, x1.device, groups)
+            self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
         if stats_hook is not None:
             stats = stats_hook(stats)
         if count_imgs is None:
             count_imgs = imgs_per_stat
         count = float(count_imgs) * S * (C // groups)
-        out = self.empty((n_img * S, C), self.act_dtype, x1.device)
+        if out is None:
+            out = self.empty((n_img * S, C), self.act_dtype, x1.device)
         self.groupnorm_apply(x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu)
         return out
 
