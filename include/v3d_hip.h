@@ -172,6 +172,15 @@ int v3d_attn_temporal(const void* q, int64_t q_sb, int64_t q_st, int64_t q_ss,
                       int64_t B, int32_t Tq, int32_t Tk, int64_t S, int32_t heads, float scale,
                       v3d_stream_t stream);
 
+/* Single-head self-attention of the VAE AttnBlock (ABI 3; reference sgm/modules/diffusionmodules/model.py:180-201: q, k, v 1x1 convs ->
+ * F.scaled_dot_product_attention over ONE head of width C -> proj_out), streamed softmax: no [S][S] tensor is ever written.
+ *   out[n][s][c] = sum_j softmax_j(q[n][s] . k[n][j] * scale) * v[n][j][c] + bias[c]
+ *   q at q + (n*S+s)*ldq, k at k + (n*S+j)*ldk (bf16, C channels), vT[n][c][j] (keys contiguous: the value projection is computed as a
+ *   swapped GEMM, its bias is added here - softmax rows sum to 1); out bf16 at out + (n*S+s)*ldo; bias fp32 [C] or NULL.
+ * C = 512 is the V3D / SVD first stage (4096 tokens at 512x512, 9216 at 576x1024); C = 256 / 128 serve reduced-width test models. */
+int v3d_attn_vae_d512(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vT, const float* bias, void* out,
+                      int64_t ldo, int64_t n_img, int64_t S, int32_t C, float scale, v3d_stream_t stream);
+
 /* Row softmax: out_bf16[r][j] = softmax_j(in_f32[r][:]) ; used by the VAE AttnBlock (model.py:190-192) in
  * its unfused (batched GEMM -> softmax -> batched GEMM) form. */
 int v3d_softmax_rows(const float* in, void* out, int64_t rows, int64_t L, v3d_stream_t stream);

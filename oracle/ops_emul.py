@@ -161,6 +161,17 @@ class EmulOps(OpsBase):
         o = F.scaled_dot_product_attention(qf, kf, vf, scale=scale)           # b s h tq d
         out.copy_(o.permute(0, 3, 1, 2, 4).reshape(B, Tq, S, C).to(out.dtype))
 
+    ATTN_VAE_WIDTHS = (128, 256, 512)
+
+    def attn_vae(self, q, k, vT, bias, out, n_img, S, C, scale):
+        qf = q[:, :C].float().reshape(n_img, 1, S, C)
+        kf = k[:, :C].float().reshape(n_img, 1, S, C)
+        vf = vT.float().reshape(n_img, 1, C, S).permute(0, 1, 3, 2)
+        o = F.scaled_dot_product_attention(qf, kf, vf, scale=scale).reshape(n_img * S, C)
+        if bias is not None:
+            o = o + bias.float()[None, :]
+        out[:, :C].copy_(o.to(out.dtype))
+
     def softmax_rows(self, inp, out):
         out.copy_(torch.softmax(inp.float(), dim=-1).to(out.dtype))
 

@@ -166,6 +166,45 @@ def case_attn_temporal(hip, emu, dev, *, B, Tq, Tk, S, heads, seed=0):
     return compare(o_h, o_e)
 
 
+def case_attn_vae(hip, emu, dev, *, n_img, S, C=512, seed=0, spike=False, bias=True):
+    """v3d_attn_vae_d512 (single head of width C, streamed softmax) vs SDPA; `spike` forces running-max jumps beyond the deferred-rescale
+    threshold late in the key sequence (cdna guide rule 26: the rare branch needs an input that takes it)."""
+    g = torch.Generator().manual_seed(seed)
+    q = _rand(g, (n_img * S, C), device=dev)
+    k = _rand(g, (n_img * S, C + 64), device=dev)[:, :C]        # strided key rows (ldk != C)
+    if spike:
+        q[7] *= 3.0
+        k[S // 2 + 3] = (q[7].float() * 4.0).to(BF)             # raw score ~ 12 |q|^2: far above every other key of query 7
+        k[S - 5] *= 9.0
+    vT = _rand(g, (n_img, C, S), device=dev)
+    b = _rand(g, (C,), F32, 0.5, dev) if bias else None
+    o_h = torch.zeros((n_img * S, C), dtype=BF, device=dev)
+    o_e = torch.zeros_like(o_h)
+    hip.attn_vae(q, k, vT, b, o_h, n_img, S, C, float(C) ** -0.5)
+    emu.attn_vae(q, k, vT, b, o_e, n_img, S, C, float(C) ** -0.5)
+    return compare(o_h, o_e)
+
+
+def case_convt3_split_halo(hip, emu, dev, *, B, T, S, N, K, first=False, last=False, seed=0):
+    """CONVT3 in the split-halo layout of frame sharding (ABI 3): [B*S halo | B*T*S local | B*S halo] rows, all B samples in one launch.
+    The halo slabs of a global end are filled with NaN: they must never be read."""
+    g = torch.Generator().manual_seed(seed)
+    M = B * T * S
+    A = _rand(g, ((B + B * T + B) * S, K), device=dev)
+    if first:
+        A[:B * S] = float("nan")
+    if last:
+        A[(B + B * T) * S:] = float("nan")
+    W = _rand(g, (3, N, K), scale=1 / math.sqrt(3 * K), device=dev)
+    kw = dict(A=A, W=W, M=M, N=N, K=K, mode=GEMM_CONVT3, T=T, S=S, tmin=0 if first else -1, tmax=T - 1 if last else T, a_row0=B * S,
+              halo_rows=B * S, bias=_rand(g, (N,), F32, 0.5, dev), res1=_rand(g, (M, N), device=dev))
+    o_h = torch.zeros((M, N), dtype=BF, device=dev)
+    o_e = torch.zeros_like(o_h)
+    hip.gemm(GemmCall(out=o_h, **kw))
+    emu.gemm(GemmCall(out=o_e, **kw))
+    return compare(o_h, o_e)
+
+
 def case_softmax(hip, emu, dev, *, rows, L, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = _rand(g, (rows, L), F32, 3.0, dev)
@@ -282,6 +321,14 @@ def all_cases(full: bool = True):
         ("attn_temporal_T3", case_attn_temporal, dict(B=2, Tq=3, Tk=3, S=4, heads=1), TOL_BF16),
         ("attn_temporal_shard_2of18", case_attn_temporal, dict(B=2, Tq=2, Tk=18, S=8, heads=2), TOL_BF16),
         ("attn_temporal_T25", case_attn_temporal, dict(B=1, Tq=25, Tk=25, S=8, heads=1), TOL_BF16),
+        ("attn_vae_C128_S64", case_attn_vae, dict(n_img=2, S=64, C=128), TOL_BF16),
+        ("attn_vae_C128_S48_ragged", case_attn_vae, dict(n_img=3, S=48, C=128, bias=False), TOL_BF16),
+        ("attn_vae_C256_S200_ragged", case_attn_vae, dict(n_img=1, S=200, C=256), TOL_BF16),
+        ("attn_vae_C512_S256", case_attn_vae, dict(n_img=2, S=256, C=512), TOL_BF16),
+        ("attn_vae_C512_spike", case_attn_vae, dict(n_img=1, S=512, C=512, spike=True), TOL_BF16),
+        ("convt3_split_halo_mid", case_convt3_split_halo, dict(B=2, T=3, S=16, N=64, K=64), TOL_BF16),
+        ("convt3_split_halo_first", case_convt3_split_halo, dict(B=2, T=2, S=40, N=72, K=64, first=True), TOL_BF16),
+        ("convt3_split_halo_last_v3", case_convt3_split_halo, dict(B=2, T=9, S=256, N=320, K=320, last=True), TOL_BF16),
         ("softmax_4096", case_softmax, dict(rows=64, L=4096), TOL_BF16),
         ("softmax_64", case_softmax, dict(rows=7, L=64), TOL_BF16),
     ]
@@ -304,6 +351,8 @@ def all_cases(full: bool = True):
             ("attn_spatial_V3D_L0", case_attn_spatial, dict(n_img=2, S=4096, heads=5), TOL_BF16),
             ("attn_spatial_V3D_L1", case_attn_spatial, dict(n_img=4, S=1024, heads=10), TOL_BF16),
             ("attn_temporal_V3D_L1", case_attn_temporal, dict(B=2, Tq=18, Tk=18, S=1024, heads=10), TOL_BF16),
+            ("attn_vae_V3D_4096", case_attn_vae, dict(n_img=2, S=4096, C=512), TOL_BF16),
+            ("attn_vae_scene_9216", case_attn_vae, dict(n_img=1, S=9216, C=512, seed=4), TOL_BF16),
             ("vae_attn_scores", case_gemm, dict(M=1024, N=1024, K=512, batch=2, bias=False, shared_w=False, out_fp32=True), TOL_BF16),
         ]
     return C

@@ -6,10 +6,10 @@ nearest-2x+conv3x3 between levels -> GroupNorm+swish -> AE3DConv.  Same channels
 kernels as the U-Net; the reference decodes in fp32 (disable_first_stage_autocast), here activations are bf16 with
 fp32 accumulation and fp32 GroupNorm statistics (tolerance: tests/test_engine_gpu.py).
 
-AttnBlock (single head, d = C = 512, 4096 tokens): q,k projections, V^T produced directly by a swapped GEMM,
-scores = q k^T * C^-1/2 as a batched GEMM into fp32, row softmax, P V^T^T as a batched GEMM.  The value bias is added
-after P.V (softmax rows sum to 1, so P (V + 1 b^T) = P V + b^T).  With 288 GB of HBM the [T, 4096, 4096] fp32 score
-tensor (1.2 GB for 18 frames) is simply materialised in this round.
+AttnBlock (single head, d = C = 512, 4096 tokens): q, k projections, V^T produced directly by a swapped GEMM, then ONE streamed-softmax
+MFMA kernel (v3d_attn_vae_d512): scores and probabilities stay in registers, nothing [S, S]-shaped is written (the first version
+materialised a 1.2 GB fp32 score tensor + 0.6 GB of probabilities per 18-frame decode; 8.1 + 4.1 GB at the 24 x 9216-token scene shape).
+The value bias is added after P.V (softmax rows sum to 1, so P (V + 1 b^T) = P V + b^T).
 """
 from __future__ import annotations
 
@@ -31,6 +31,12 @@ def run_vae_attn(env: Env, g: Geo, p: AttnPack, x: torch.Tensor) -> torch.Tensor
     k = ops.linear(hn, *p.wk)
     vT = ops.empty((n, C, S), None, x.device)
     ops.gemm(GemmCall(A=p.wv, W=hn.view(n, S, C), out=vT, M=C, N=S, K=C, batch=n))
+    if C in getattr(ops, "ATTN_VAE_WIDTHS", ()) and S % 8 == 0:
+        # streamed-softmax MFMA kernel: the [n, S, S] scores never exist (model.py:180-201 is SDPA in the reference too)
+        o = ops.empty((n * S, C), None, x.device)
+        ops.attn_vae(q, k, vT, p.bv, o, n, S, C, float(C) ** -0.5)
+        return ops.linear(o, p.proj[0], p.proj[1], res1=x)
+    # other widths (not used by V3D / SVD): batched GEMM -> fp32 scores -> row softmax -> batched GEMM
     scores = ops.empty((n, S, S), F32, x.device)
     ops.gemm(GemmCall(A=q.view(n, S, C), W=k.view(n, S, C), out=scores, M=S, N=S, K=C, batch=n, c_acc=float(C) ** -0.5))
     prob = ops.empty((n, S, S), None, x.device)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "v3d_attn_spatial": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "v3d_attn_temporal": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64,
                                   c_i64, c_i64, c_i32, c_i32, c_i64, c_i32, c_f32, c_vp]),
+    "v3d_attn_vae_d512": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "v3d_softmax_rows": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_timestep_embedding": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "v3d_silu_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -241,6 +242,17 @@ class HipOps(OpsBase):
                                                k.data_ptr(), v.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
                                                out.data_ptr(), out.stride(0), out.stride(1), out.stride(2),
                                                B, Tq, Tk, S, heads, float(scale), self._stream()), "v3d_attn_temporal")
+
+    ATTN_VAE_WIDTHS = (128, 256, 512)
+
+    def attn_vae(self, q, k, vT, bias, out, n_img, S, C, scale):
+        """Single-head attention of the VAE AttnBlock: q / k [n_img * S, C] views, vT [n_img, C, S], bias [C] fp32 or None."""
+        bf = torch.bfloat16
+        self._req(q, bf, "attn_vae.q"); self._req(k, bf, "attn_vae.k"); self._req_c(vT, bf, "attn_vae.vT"); self._req(out, bf, "attn_vae.out")
+        if bias is not None:
+            self._req_c(bias, torch.float32, "attn_vae.bias")
+        self._check(self.lib.v3d_attn_vae_d512(q.data_ptr(), q.stride(-2), k.data_ptr(), k.stride(-2), vT.data_ptr(), _ptr(bias), out.data_ptr(),
+                                               out.stride(-2), n_img, S, C, float(scale), self._stream()), "v3d_attn_vae_d512")
 
     def softmax_rows(self, inp, out):
         self._req_c(inp, torch.float32, "softmax.in"); self._req_c(out, torch.bfloat16, "softmax.out")
