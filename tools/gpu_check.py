@@ -38,7 +38,15 @@ def bench(hip):
     dev = "cuda"
     out = []
 
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    only = only[0] if only else None
+
+    def want(name):
+        return only is None or any(o in name for o in only)
+
     def gemm_case(name, M, N, K, mode=GEMM_LINEAR, geglu=False, conv=None, convt=None, res=False):
+        if not want(name):
+            return
         kw = {}
         taps = 1
         a_rows = M
@@ -92,6 +100,8 @@ def bench(hip):
     gemm_case("vae_conv_64sq_512", 0, 512, 512, GEMM_CONV3X3, conv=(18, 64, 64, 1, 1))
 
     def attn_case(name, n_img, S, heads):
+        if not want(name):
+            return
         C = heads * 64
         qk = torch.randn(n_img * S, 2 * C, device=dev).to(BF)
         vT = torch.randn(n_img, C, S, device=dev).to(BF)
@@ -107,6 +117,8 @@ def bench(hip):
     attn_case("attn_L3", 36, 64, 20)
 
     def tattn_case(name, B, T, S, heads):
+        if not want(name):
+            return
         C = heads * 64
         qkv = torch.randn(B, T, S, 3 * C, device=dev).to(BF)
         o = torch.empty(B, T, S, C, dtype=BF, device=dev)
@@ -120,6 +132,8 @@ def bench(hip):
     tattn_case("tattn_L2", 2, 18, 256, 20)
 
     def gn_case(name, n_img, S, C, ips=1):
+        if not want(name):
+            return
         x = torch.randn(n_img * S, C, device=dev).to(BF)
         ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
         ms = timeit(lambda: hip.groupnorm(x, None, ga, be, n_img, S, eps=1e-5, silu=True, imgs_per_stat=ips))
@@ -134,6 +148,8 @@ def bench(hip):
     gn_case("gn_vae_512sq_128", 18, 512 * 512, 128)
 
     def ln_case(name, M, C):
+        if not want(name):
+            return
         x = torch.randn(M, C, device=dev).to(BF)
         ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
         o = torch.empty_like(x)
@@ -141,6 +157,21 @@ def bench(hip):
         byt = x.numel() * 2 * 2
         out.append(dict(name=name, ms=ms, gbps=byt / ms / 1e6))
         print(f"{name:34s} M={M} C={C}  {ms:8.3f} ms  {byt / ms / 1e6:8.1f} GB/s", flush=True)
+
+    def vattn_case(name, n_img, S, C=512):
+        if not want(name):
+            return
+        q = torch.randn(n_img * S, C, device=dev).to(BF)
+        k = torch.randn(n_img * S, C, device=dev).to(BF)
+        vT = torch.randn(n_img, C, S, device=dev).to(BF)
+        o = torch.empty(n_img * S, C, dtype=BF, device=dev)
+        ms = timeit(lambda: hip.attn_vae(q, k, vT, None, o, n_img, S, C, C ** -0.5))
+        flop = 4.0 * n_img * S * S * C
+        out.append(dict(name=name, ms=ms, tflops=flop / ms / 1e9))
+        print(f"{name:34s} n={n_img} S={S} C={C}  {ms:8.3f} ms  {flop / ms / 1e9:8.1f} TF/s (algorithmic 4 S^2 C)", flush=True)
+
+    vattn_case("attn_vae_18x4096", 18, 4096)
+    vattn_case("attn_vae_scene_24x9216", 24, 9216)
 
     ln_case("ln_L0", 36 * 4096, 320)
     ln_case("ln_L1", 36 * 1024, 640)
@@ -160,7 +191,11 @@ def main():
     results = []
     if "--no-check" not in sys.argv:
         nfail = 0
+        only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+        only = only[0] if only else None
         for name, fn, kw, tol in op_cases.all_cases(full=True):
+            if only is not None and not any(o in name for o in only):
+                continue
             t0 = time.time()
             try:
                 if fn is op_cases.case_elementwise:
@@ -175,7 +210,7 @@ def main():
             results.append(dict(name=name, rel=rel, cos=cos, ok=ok, err=err))
             print(f"{'PASS' if ok else 'FAIL'} {name:34s} rel={rel:.3e} cos={cos:.6f} {time.time() - t0:.2f}s {err}", flush=True)
         try:
-            for k, (rel, cos) in op_cases.case_elementwise(hip, emu, "cuda").items():
+            for k, (rel, cos) in (op_cases.case_elementwise(hip, emu, "cuda").items() if only is None else ()):
                 tol = op_cases.TOL_BF16 if k in ("timestep_embedding", "timestep_embedding_odd", "silu_add", "silu", "pack_input",
                                                  "pack_input_pad", "nchw_to_nhwc", "copy2d") else 1e-4
                 ok = rel <= tol
