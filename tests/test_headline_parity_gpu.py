@@ -147,12 +147,18 @@ def test_sampler_steps_teacher_forced(golden, kind, key):
 
     x = noise.clone() * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     prev_max = float(x.abs().max())
+    amp = 1.0
     it = iter(calls)
     for i in range(p["steps"]):
         inp, sig, _, out = next(it)
         # (x_{i+1} = x + dt d cancels a state of magnitude |x_i| down to |x_{i+1}|: fp32 rounding of the LARGER state is the honest bound)
-        assert torch.allclose(inp[: x.shape[0]], x, rtol=1e-4, atol=4e-6 * prev_max), (i, (inp[: x.shape[0]] - x).abs().max().item(), prev_max)
+        assert torch.allclose(inp[: x.shape[0]], x, rtol=1e-4, atol=4e-6 * prev_max * amp), (i, (inp[: x.shape[0]] - x).abs().max().item(), prev_max, amp)
         prev_max = float(x.abs().max())
+        # Heun's d_new = (euler - denoised2) / next_sigma divides a difference of nearly equal fp32 numbers by next_sigma: the rounding of
+        # that difference comes back multiplied by |dt| / (2 next_sigma) (7800 / 2 for the 15.59 -> 0.002 step) - in the reference too
+        amp = 1.0
+        if kind.startswith("heun") and float(sigmas[i + 1]) > 0:
+            amp += float((sigmas[i] - sigmas[i + 1]) / sigmas[i + 1]) / 2.0
         d = (x - guided(out)) / sigmas[i]
         euler = x + (sigmas[i + 1] - sigmas[i]) * d
         if kind.startswith("heun") and float(sigmas[i + 1]) > 0:
