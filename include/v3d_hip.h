@@ -162,6 +162,21 @@ int v3d_layernorm(const void* x, const float* add, int64_t add_rpg, int64_t add_
 int v3d_attn_spatial(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vT, void* out,
                      int64_t ldo, int64_t n_img, int64_t S, int32_t heads, float scale, v3d_stream_t stream);
 
+/* fp8 (OCP e4m3fn) variant of the spatial self-attention (ABI 3) - BASELINE.json configs[4] ("scene" shape, 9216 tokens at level 0) names
+ * fp8 MFMA attention; the reference has no fp8 path, parity is stated against v3d_attn_spatial (tests: cosine >= 0.995).  Never used by the
+ * headline benchmark.  Three steps:
+ *   v3d_quant_fp8_tiles: x [n_img*S][ldx] bf16, first `ncols` columns (the q | k projection, ncols = 2*heads*64) -> x8 [n_img*S][ld8] e4m3 bytes
+ *     and scales[n_img][ceil(S/64)][ncols/64] fp32: one dequantisation factor (amax / 448) per 64-row x 64-column tile.
+ *   v3d_quant_fp8_slab:  vT [n_img][heads*64][S] bf16 -> v8 (same shape, e4m3) and vscale[n_img][heads]: one factor per (image, head) slab
+ *     (`amax_scratch`: n_img*heads uint32 of device scratch).
+ *   v3d_attn_spatial_fp8: out = softmax(q k^T * scale) v on v_mfma_f32_32x32x64_f8f6f4 (QK^T and P.V both fp8 x fp8 -> fp32; P as e4m3(256 p)),
+ *     q at qk8 + (n*S+s)*ld8 + h*64, k at the same row + heads*64; out bf16 [n_img*S][ldo].  S % 16 == 0. */
+int v3d_quant_fp8_tiles(const void* x, int64_t ldx, void* x8, int64_t ld8, float* scales, int64_t n_img, int64_t S, int32_t ncols,
+                        v3d_stream_t stream);
+int v3d_quant_fp8_slab(const void* vT, void* v8, float* vscale, void* amax_scratch, int64_t n_img, int64_t S, int32_t heads, v3d_stream_t stream);
+int v3d_attn_spatial_fp8(const void* qk8, int64_t ld8, const float* scales, const void* v8, const float* vscale, void* out, int64_t ldo,
+                         int64_t n_img, int64_t S, int32_t heads, float scale, v3d_stream_t stream);
+
 /* Temporal self-attention over the frame axis (Tq local queries x Tk keys, Tq,Tk <= 32), head dim 64.
  *   problem p = (b, s, h); element (b, t, s, h*64+d) of q at q + b*q_sb + t*q_st + s*q_ss + h*64 + d (same for k, v, out).
  * replaces VideoTransformerBlock.attn1 on "(b t) s c -> (b s) t c" (video_attention.py:114,122-125) without the

@@ -161,6 +161,38 @@ class EmulOps(OpsBase):
         o = F.scaled_dot_product_attention(qf, kf, vf, scale=scale)           # b s h tq d
         out.copy_(o.permute(0, 3, 1, 2, 4).reshape(B, Tq, S, C).to(out.dtype))
 
+    # ---- fp8 attention: tile-scaled e4m3 quantisation restated with torch.float8_e4m3fn, attention on the dequantised operands ----
+    def quant_fp8_tiles(self, x, n_img, S):
+        ncols = x.shape[-1]
+        nt = (S + 63) // 64
+        xf = x.float().reshape(n_img, S, ncols)
+        pad = nt * 64 - S
+        xp = F.pad(xf, (0, 0, 0, pad)).reshape(n_img, nt, 64, ncols // 64, 64)
+        amax = xp.abs().amax(dim=(2, 4))                                             # [n, nt, ncols / 64]
+        scales = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        q = (xp / scales[:, :, None, :, None]).to(torch.float8_e4m3fn)
+        x8 = q.view(torch.uint8).reshape(n_img, nt * 64, ncols)[:, :S].reshape(n_img * S, ncols).contiguous()
+        return x8, scales.contiguous()
+
+    def quant_fp8_slab(self, vT, heads):
+        n_img, C, S = vT.shape
+        vf = vT.float().reshape(n_img, heads, 64, S)
+        amax = vf.abs().amax(dim=(2, 3))
+        vscale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        v8 = (vf / vscale[:, :, None, None]).to(torch.float8_e4m3fn).view(torch.uint8).reshape(n_img, C, S).contiguous()
+        return v8, vscale.contiguous()
+
+    def attn_spatial_fp8(self, qk8, scales, v8, vscale, out, n_img, S, heads, scale):
+        C = heads * 64
+        nt = scales.shape[1]
+        deq = qk8.view(torch.float8_e4m3fn).float().reshape(n_img, S, 2 * heads, 64)
+        rows = torch.arange(S, device=qk8.device) // 64
+        deq = deq * scales[:, rows][..., None]                                       # [n, S, 2 heads, 64]
+        qf, kf = deq[:, :, :heads].permute(0, 2, 1, 3), deq[:, :, heads:].permute(0, 2, 1, 3)
+        vf = v8.view(torch.float8_e4m3fn).float().reshape(n_img, heads, 64, S) * vscale[:, :, None, None]
+        o = F.scaled_dot_product_attention(qf, kf, vf.permute(0, 1, 3, 2), scale=scale)
+        out[:, :C].copy_(o.permute(0, 2, 1, 3).reshape(n_img * S, C).to(out.dtype))
+
     ATTN_VAE_WIDTHS = (128, 256, 512)
 
     def attn_vae(self, q, k, vT, bias, out, n_img, S, C, scale):

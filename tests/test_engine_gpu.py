@@ -81,6 +81,31 @@ def test_unet_vs_oracle_other_shapes(T, H, W, B2):
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
 
 
+def test_scene_shape_vs_oracle():
+    """BASELINE.json configs[4] shape (T = 24 frames, 576 x 1024 -> 72 x 128 latents: 9216 / 2304 / 576 / 144 tokens per level, none a
+    power of two) at reduced width against the fp32 oracle - the same U-Net graph as the headline config, other tile counts, ragged
+    attention tiles (144 = 2.25 x 64 keys) and a 24-frame temporal axis."""
+    from conftest import record_parity
+    from oracle import sgm_oracle as O
+    from v3d_amd import synth
+    T, H, W = 24, 72, 128
+    g = torch.Generator().manual_seed(321)
+    n = 2 * T
+    x8, ts = torch.randn(n, 8, H, W, generator=g), torch.randn(n, generator=g)
+    ctx, y = torch.randn(n, 1, 1024, generator=g), torch.randn(n, 768, generator=g)
+    ioi = torch.zeros(2, T)
+    net = build_unet(DEV)
+    out = net(x8.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi.to(DEV)).float().cpu()
+    sd = {k: v.float().cpu() for k, v in net.state_dict().items()}
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 32))
+    ref = O.unet_forward(sd, synth.unet_config(TINY["model_channels"]), x8, ts, ctx, y, T, ioi)
+    torch.set_num_threads(nthr)
+    rel, cos = rel_cos(out, ref)
+    record_parity("scene_shape_unet_eval_width64", {"T": T, "latent": [H, W], "images": n, "max_rel_err": round(rel, 5), "cosine": round(cos, 6)})
+    assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
+
+
 # ---- BASELINE.json configs[1] sizes (width 320, 64 x 64 latents, 18 frames, cfg-doubled) --------------------------------------
 
 def test_full_size_batch_independence(full_unet):

@@ -66,7 +66,13 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     vT = ops.empty((n, C, S), ops.act_dtype, x.device)
     ops.gemm(GemmCall(A=p.s_wv, W=n1.view(n, S, C), out=vT, M=C, N=S, K=C, batch=n))
     a = ops.empty((n * S, C), ops.act_dtype, x.device)
-    ops.attn_spatial(qk[:, :C], qk[:, C:], vT, a, n, S, p.heads, 0.125)
+    if os.environ.get("V3D_ATTN_FP8", "0") not in ("", "0") and hasattr(ops, "attn_spatial_fp8") and S % 16 == 0:
+        # scene-config variant (BASELINE.json configs[4]): e4m3 q | k tiles and V^T slabs, QK^T and P.V on the K = 64 fp8 MFMA
+        qk8, qk_scales = ops.quant_fp8_tiles(qk, n, S)
+        v8, v_scale = ops.quant_fp8_slab(vT, p.heads)
+        ops.attn_spatial_fp8(qk8, qk_scales, v8, v_scale, a, n, S, p.heads, 0.125)
+    else:
+        ops.attn_spatial(qk[:, :C], qk[:, C:], vT, a, n, S, p.heads, 0.125)
     # x = attn1 + x, then attn2 (1 context token => a per-image vector, Appendix B-9) folded in the same epilogue
     x = ops.linear(a, p.s_wo[0], p.s_wo[1], res1=x, add=ctx[:, p.s_ctx_off:], add_rpg=S, add_ld=ctx_ld)
     ga, be, eps = p.s_norm3

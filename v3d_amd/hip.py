@@ -58,6 +58,9 @@ SIGNATURES = {
     "v3d_attn_temporal": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64,
                                   c_i64, c_i64, c_i32, c_i32, c_i64, c_i32, c_f32, c_vp]),
     "v3d_attn_vae_d512": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
+    "v3d_quant_fp8_tiles": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "v3d_quant_fp8_slab": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "v3d_attn_spatial_fp8": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "v3d_softmax_rows": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "v3d_timestep_embedding": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "v3d_silu_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -253,6 +256,35 @@ class HipOps(OpsBase):
             self._req_c(bias, torch.float32, "attn_vae.bias")
         self._check(self.lib.v3d_attn_vae_d512(q.data_ptr(), q.stride(-2), k.data_ptr(), k.stride(-2), vT.data_ptr(), _ptr(bias), out.data_ptr(),
                                                out.stride(-2), n_img, S, C, float(scale), self._stream()), "v3d_attn_vae_d512")
+
+    # ---- fp8 attention (scene config; never used by the headline benchmark) ------------------------------
+    def quant_fp8_tiles(self, x, n_img, S):
+        """x [n_img * S, ncols] bf16 view -> (x8 [n_img * S, ncols] uint8 e4m3 bytes, scales [n_img, ceil(S / 64), ncols / 64] fp32)."""
+        self._req(x, torch.bfloat16, "quant_fp8_tiles.x")
+        ncols = x.shape[-1]
+        x8 = torch.empty((n_img * S, ncols), dtype=torch.uint8, device=x.device)
+        scales = torch.empty((n_img, (S + 63) // 64, ncols // 64), dtype=torch.float32, device=x.device)
+        self._check(self.lib.v3d_quant_fp8_tiles(x.data_ptr(), x.stride(-2), x8.data_ptr(), ncols, scales.data_ptr(), n_img, S, ncols, self._stream()),
+                    "v3d_quant_fp8_tiles")
+        return x8, scales
+
+    def quant_fp8_slab(self, vT, heads):
+        """vT [n_img, heads * 64, S] bf16 -> (v8 uint8 e4m3 bytes of the same shape, vscale [n_img, heads] fp32)."""
+        self._req_c(vT, torch.bfloat16, "quant_fp8_slab.vT")
+        n_img, _, S = vT.shape
+        v8 = torch.empty(vT.shape, dtype=torch.uint8, device=vT.device)
+        vscale = torch.empty((n_img, heads), dtype=torch.float32, device=vT.device)
+        scratch = torch.empty((n_img, heads), dtype=torch.int32, device=vT.device)
+        self._check(self.lib.v3d_quant_fp8_slab(vT.data_ptr(), v8.data_ptr(), vscale.data_ptr(), scratch.data_ptr(), n_img, S, heads, self._stream()),
+                    "v3d_quant_fp8_slab")
+        return v8, vscale
+
+    def attn_spatial_fp8(self, qk8, scales, v8, vscale, out, n_img, S, heads, scale):
+        self._req_c(qk8, torch.uint8, "attn_fp8.qk8"); self._req_c(v8, torch.uint8, "attn_fp8.v8")
+        self._req_c(scales, torch.float32, "attn_fp8.scales"); self._req_c(vscale, torch.float32, "attn_fp8.vscale")
+        self._req(out, torch.bfloat16, "attn_fp8.out")
+        self._check(self.lib.v3d_attn_spatial_fp8(qk8.data_ptr(), qk8.stride(-2), scales.data_ptr(), v8.data_ptr(), vscale.data_ptr(), out.data_ptr(),
+                                                  out.stride(-2), n_img, S, heads, float(scale), self._stream()), "v3d_attn_spatial_fp8")
 
     def softmax_rows(self, inp, out):
         self._req_c(inp, torch.float32, "softmax.in"); self._req_c(out, torch.bfloat16, "softmax.out")
