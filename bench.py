@@ -189,6 +189,10 @@ class _Timed:
         self._wrap("groupnorm_stats", m_gns)
         self._wrap("groupnorm_apply", m_gna)
         self._wrap("layernorm", m_ln)
+        if hasattr(self.ops, "attn_spatial_fp8"):     # scene-config variant (V3D_ATTN_FP8=1): attention + its two quantisation passes
+            self._wrap("attn_spatial_fp8", lambda qk8, sc, v8, vs, out, n_img, S, heads, scale: ("attn_spatial_fp8", 4.0 * n_img * heads * S * S * 64, 3 * n_img * S * heads * 64 + n_img * S * heads * 128))
+            self._wrap("quant_fp8_tiles", lambda x, n_img, S: ("quant_fp8", 0.0, x.shape[0] * x.shape[1] * 3))
+            self._wrap("quant_fp8_slab", lambda vT, heads: ("quant_fp8", 0.0, vT.numel() * 5))
         if hasattr(self.ops, "attn_vae"):
             self._wrap("attn_vae", lambda q, k, v, out, n_img, S, C, scale: ("attn_vae_d512", 4.0 * n_img * S * S * C, 4 * n_img * S * C * 2))
         return self

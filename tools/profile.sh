@@ -19,3 +19,5 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o pf -- python
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw -- python $R/tools/pmc_eval.py > $R/gpurun_out/${TAG}_pmc_w.log 2>&1
 cd $R
 python tools/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) 2 gpurun_out/${TAG}_pmc_traffic.json | tee gpurun_out/${TAG}_pmc_traffic.txt
+# which launches carry the traffic: per-shape-class measured vs algorithmic bytes (call list written by pmc_eval.py)
+python tools/pmc_per_launch.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) gpurun_out/pmc_eval_calls.json | tee gpurun_out/${TAG}_pmc_per_launch.txt

@@ -147,8 +147,54 @@ class HipOps(OpsBase):
         return t
 
     # ---- primitives -------------------------------------------------------------------------------
+    _MAX_OPERAND_BYTES = 0xFFFFFF00      # one hardware buffer descriptor (v3d_gemm's A / W operands)
+
+    def _gemm_in_row_chunks(self, g: GemmCall) -> bool:
+        """An activation operand beyond one buffer descriptor (> 4 GiB: the 24-frame 576 x 1024 scene decode has a 7.2 GB conv input)
+        is contracted in chunks of whole images (conv3x3) / rows (linear): every row-indexed argument is sliced consistently."""
+        import dataclasses
+        import math
+        if g.batch != 1 or g.mode == 2 or g.A.dim() != 2:
+            return False
+        lda = g.A.stride(0)
+        rows_in = g.A.shape[0]
+        if rows_in * lda * 2 <= self._MAX_OPERAND_BYTES:
+            return False
+        if g.mode == 1:
+            s_out, s_in = g.Hout * g.Wout, g.Hin * g.Win
+        else:
+            s_out = s_in = 1
+        align = 1
+        for rpg in (g.add_rpg if g.add is not None else 0, g.coef_rpg if g.coef is not None else 0, g.gn_rps if g.gn_stats is not None else 0):
+            if rpg:
+                align = align * rpg // math.gcd(align, rpg)
+        unit_out = s_out * align // math.gcd(s_out, align)          # output rows per indivisible unit
+        unit_in = unit_out // s_out * s_in
+        units = g.M // unit_out
+        if units * unit_out != g.M:
+            raise RuntimeError("gemm: operand larger than 4 GiB and M is not a whole number of images / row groups")
+        per = max(1, int((self._MAX_OPERAND_BYTES // 2) // (unit_in * lda * 2)))
+        for u0 in range(0, units, per):
+            u1 = min(units, u0 + per)
+            r0, r1 = u0 * unit_out, u1 * unit_out
+            kw = dict(A=g.A[u0 * unit_in:u1 * unit_in], out=g.out[r0:r1], M=r1 - r0, a_rows=0)
+            if g.res1 is not None:
+                kw["res1"] = g.res1[r0:r1]
+            if g.res2 is not None:
+                kw["res2"] = g.res2[r0:r1]
+            if g.add is not None:
+                kw["add"] = g.add[r0 // g.add_rpg:]
+            if g.coef is not None:
+                kw["coef"] = g.coef.reshape(-1, 3)[r0 // g.coef_rpg:].contiguous()
+            if g.gn_stats is not None:
+                kw["gn_stats"] = g.gn_stats[r0 // g.gn_rps:]
+            self.gemm(dataclasses.replace(g, **kw))
+        return True
+
     def gemm(self, g: GemmCall):
         bf, f32 = torch.bfloat16, torch.float32
+        if self._gemm_in_row_chunks(g):
+            return
         a = _GemmArgs()
         self._req(g.A, bf, "gemm.A")
         self._req(g.W, bf, "gemm.W")
