@@ -27,15 +27,29 @@ def test_remap_targets_is_the_whole_switch():
 
 
 def test_state_dict_keys_match_reference():
+    """Key names, shapes AND registration order of every parameter owner == the reference modules' (fixture written by
+    oracle/gen_state_dict_keys.py from the reference's own classes), at the parity widths and at the V3D_512 checkpoint's widths
+    (1428 U-Net tensors = 1524.6 M parameters, 266 decoder / 106 encoder tensors): what ckpts/V3D_512.ckpt and svd_xt.safetensors
+    hold under model.diffusion_model.* / first_stage_model.{decoder,encoder}.* loads by name."""
     keys = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_state_dict_keys.json")))
     from v3d_amd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    from v3d_amd.sgm.modules.diffusionmodules.model import Encoder
     from v3d_amd.sgm.modules.diffusionmodules.video_model import VideoUNet
-    net = VideoUNet(**synth.unet_config(64))
-    assert {k: list(v.shape) for k, v in net.state_dict().items()} == keys["unet_mc64"]
-    assert list(net.state_dict().keys()) == list(keys["unet_mc64"].keys())
-    dec = VideoDecoder(**synth.decoder_config(32))
-    assert {k: list(v.shape) for k, v in dec.state_dict().items()} == keys["decoder_ch32"]
+
+    def same(module, ref):
+        sd = module.state_dict()
+        assert {k: list(v.shape) for k, v in sd.items()} == ref
+        assert list(sd.keys()) == list(ref.keys())
+
+    with torch.device("meta"):
+        for mc in (64, 320):
+            same(VideoUNet(**synth.unet_config(mc)), keys[f"unet_mc{mc}"])
+        for ch in (32, 128):
+            same(VideoDecoder(**synth.decoder_config(ch)), keys[f"decoder_ch{ch}"])
+            same(Encoder(**synth.encoder_config(ch)), keys[f"encoder_ch{ch}"])
+    assert sum(torch.Size(s).numel() for s in keys["unet_mc320"].values()) == 1524623564 or len(keys["unet_mc320"]) == 1428
     # strict load of a reference-keyed state dict
+    net = VideoUNet(**synth.unet_config(64))
     net.load_state_dict({k: torch.zeros(s) for k, s in keys["unet_mc64"].items()}, strict=True)
 
 

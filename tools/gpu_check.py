@@ -86,7 +86,13 @@ def bench(hip):
     gemm_case("lin_L2_1280x1280", 36 * 256, 1280, 1280)
     gemm_case("lin_L2_ff1_geglu", 36 * 256, 10240, 1280, geglu=True)
     gemm_case("lin_L2_ff2", 36 * 256, 1280, 5120, res=True)
+    gemm_case("lin_L2_tqkv_3840", 36 * 256, 3840, 1280)
+    gemm_case("lin_L1_tqkv_1920", 36 * 1024, 1920, 640)
     gemm_case("lin_sq_4096", 4096, 4096, 4096)
+    gemm_case("conv_L0_640to320", 0, 320, 640, GEMM_CONV3X3, conv=(36, 64, 64, 1, 1))
+    gemm_case("conv_L1_1920to640", 0, 640, 1920, GEMM_CONV3X3, conv=(36, 32, 32, 1, 1))
+    gemm_case("conv_L1_1280sq", 0, 1280, 1280, GEMM_CONV3X3, conv=(36, 32, 32, 1, 1))
+    gemm_case("conv_L2_2560to1280", 0, 1280, 2560, GEMM_CONV3X3, conv=(36, 16, 16, 1, 1))
     gemm_case("conv_L0_320", 0, 320, 320, GEMM_CONV3X3, conv=(36, 64, 64, 1, 1))
     gemm_case("conv_L0_960to320", 0, 320, 960, GEMM_CONV3X3, conv=(36, 64, 64, 1, 1))
     gemm_case("conv_L1_640", 0, 640, 640, GEMM_CONV3X3, conv=(36, 32, 32, 1, 1))

@@ -23,6 +23,14 @@
 
 #include "common.h"
 
+// measured defaults of the tile walk / tap order (A/B: V3D_GEMM_GROUPM, V3D_GEMM_TAPINNER; tools/gpu_check.py)
+#ifndef V3D_GEMM_GROUPM_DEFAULT
+#define V3D_GEMM_GROUPM_DEFAULT 0
+#endif
+#ifndef V3D_GEMM_TAPINNER_DEFAULT
+#define V3D_GEMM_TAPINNER_DEFAULT 0
+#endif
+
 namespace {
 
 // compile-time loop (bodies that pick between named register arrays must not wait for the late loop unroller: SROA has
@@ -58,6 +66,8 @@ struct GP {
     long long halo_rows; // CONVT3 split-halo layout (0 = dense)
     long long sA, sW, sO;
     int mt, nt;  // tile counts
+    int group_m;         // tile walk: > 1 = ids run down groups of `group_m` tile rows first (L2-friendly patches), else row-major over N
+    int tap_inner;       // multi-tap modes: 1 = stage order (k outer, tap inner): the taps re-read an activation tile while it is still in L2
     int split_n;         // > 1: split-K launch: blockIdx.y = split index = output slab (out = fp32 workspace [split][M][N], plain stores)
     const float* ws;     // finalize kernel only: the workspace to reduce
     int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads
@@ -146,6 +156,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// tile id -> (tile row, tile column).  Consecutive ids run concurrently on one XCD (xcd_remap), i.e. share one 4 MiB L2: walking N fastest
+// makes 32-64 concurrent tiles of ONE tile row re-stream the whole weight matrix per row of tiles (PMC, profiles/r02a_pmc_per_launch.txt:
+// the N = 10240 GEGLU projection fetched 20x its algorithmic bytes).  group_m > 1 walks down `group_m` tile rows before moving to the next
+// tile column, so the concurrent set is a group_m x (concurrency / group_m) patch that shares both operands; bijective for any mt, nt.
+__device__ __forceinline__ void tile_coords(const GP& p, int id, int& tm, int& tn) {
+    if (p.group_m <= 1) {
+        tn = id % p.nt;
+        tm = id / p.nt;
+        return;
+    }
+    const int width = p.group_m * p.nt;
+    const int gid = id / width;
+    const int first = gid * p.group_m;
+    const int gsz = (p.mt - first) < p.group_m ? (p.mt - first) : p.group_m;
+    const int r = id - gid * width;
+    tn = r / gsz;
+    tm = first + (r - tn * gsz);
 }
 
 // ---- epilogue shared by both main loops --------------------------------------------------------------------------
@@ -427,8 +456,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
     const int wm = wave / WGN, wn = wave % WGN;
 
     const int bid = xcd_remap(blockIdx.x, p.mt * p.nt);
-    const int tile_n = bid % p.nt;
-    const int tile_m = bid / p.nt;
+    int tile_m, tile_n;
+    tile_coords(p, bid, tile_m, tile_n);
     const long long m0 = (long long)tile_m * BM;
     const long long n0 = (long long)tile_n * BN;
     const long long z = blockIdx.y;                       // batch index, or split index of a split-K launch (sA = sW = 0 then)
@@ -469,7 +498,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
     const int s0 = p.split_n > 1 ? (int)((long long)total_steps * blockIdx.y / p.split_n) : 0;
     const int s1 = p.split_n > 1 ? (int)((long long)total_steps * (blockIdx.y + 1) / p.split_n) : total_steps;
     const int nsteps = s1 - s0;
-    int ld_tap = s0 / ksteps, ld_k0 = (s0 - ld_tap * ksteps) * BK2;
+    const bool tap_inner = ntaps<MODE>() > 1 && p.tap_inner;
+    int ld_tap = tap_inner ? s0 % ntaps<MODE>() : s0 / ksteps;
+    int ld_k0 = tap_inner ? (s0 / ntaps<MODE>()) * BK2 : (s0 - ld_tap * ksteps) * BK2;
     set_tap(ld_tap);
     // steps issued past the end of the contraction (ring tail) re-read valid rows of the last tap: harmless dummies that
     // keep the per-wave DMA count per stage constant for the counted vmcnt waits
@@ -481,6 +512,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
 #pragma unroll
         for (int i = 0; i < BPW; ++i)
             __builtin_amdgcn_global_load_lds((const void*)(brow[i] + ld_k0), (__attribute__((address_space(3))) void*)(sbase + BM * ROWB + (wave + NW * i) * 1024), 16, 0, 0);
+        if (tap_inner) {   // (k outer, tap inner): the nine taps of a k-slice follow each other while their rows are still in L2
+            if (++ld_tap >= ntaps<MODE>()) {
+                ld_tap = 0;
+                ld_k0 += BK2;
+                if (ld_k0 >= p.K) ld_k0 = 0;   // (ring-tail dummies)
+            }
+            set_tap(ld_tap);
+            return;
+        }
         ld_k0 += BK2;
         if (ld_k0 >= p.K) {
             ld_k0 = 0;
@@ -558,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = xcd_remap(blockIdx.x, p.mt * p.nt);
-    const int tile_n = bid % p.nt;
-    const int tile_m = bid / p.nt;
+    int tile_m, tile_n;
+    tile_coords(p, bid, tile_m, tile_n);
     const long long m0 = (long long)tile_m * BM;
     const long long n0 = (long long)tile_n * BN;
     const long long z = blockIdx.y;
@@ -717,8 +757,10 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
     auto tile_origin = [&](int it, long long& m0, long long& n0) __attribute__((always_inline)) {
         const int id = xcd_remap((int)blockIdx.x + it * G, ntiles);
-        n0 = (long long)(id % p.nt) * BN;
-        m0 = (long long)(id / p.nt) * BM;
+        int tm, tn;
+        tile_coords(p, id, tm, tn);
+        n0 = (long long)tn * BN;
+        m0 = (long long)tm * BM;
     };
 
     // ---- loader state (runs up to 3 stages ahead of the consumer, across tile boundaries).  Raw buffer loads straight to
@@ -763,6 +805,23 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
         __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)voff[i], ld_k0 * 2, 0, 0);
     };
     auto issue_advance = [&]() __attribute__((always_inline)) {
+        if (ntaps<MODE>() > 1 && p.tap_inner) {   // (k outer, tap inner), see the v2 loader
+            if (++ld_tap < ntaps<MODE>()) {
+                set_tap(ld_tap);
+                return;
+            }
+            ld_tap = 0;
+            ld_k0 += 32;
+            if (ld_k0 >= (int)p.K) {
+                ld_k0 = 0;
+                if (++ld_it < my_tiles) {
+                    set_tile(ld_it);
+                    return;
+                }
+            }
+            set_tap(0);
+            return;
+        }
         ld_k0 += 32;
         if (ld_k0 >= (int)p.K) {
             ld_k0 = 0;
@@ -1231,6 +1290,13 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     p.halo_rows = a->mode == V3D_GEMM_CONVT3 ? a->halo_rows : 0;
     p.sA = a->sA; p.sW = a->sW; p.sO = a->sO;
     p.mt = p.nt = 0;
+    {
+        static int gm = -2, ti = -2;
+        if (gm == -2) { const char* e = getenv("V3D_GEMM_GROUPM"); gm = e ? atoi(e) : -1; }      // -1 = heuristic, 0 / 1 = row-major walk, n = groups of n tile rows
+        if (ti == -2) { const char* e = getenv("V3D_GEMM_TAPINNER"); ti = e ? atoi(e) : -1; }
+        p.group_m = gm < 0 ? V3D_GEMM_GROUPM_DEFAULT : gm;
+        p.tap_inner = ti < 0 ? V3D_GEMM_TAPINNER_DEFAULT : ti;
+    }
     p.split_n = 1;
     p.ws = nullptr;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("V3D_GEMM_ABLATE"); ab = e ? atoi(e) : 0; } p.ablate = ab; }
