@@ -23,10 +23,13 @@
 
 #include "common.h"
 
-// measured defaults of the tile walk / tap order (A/B: V3D_GEMM_GROUPM, V3D_GEMM_TAPINNER; tools/gpu_check.py)
-#ifndef V3D_GEMM_GROUPM_DEFAULT
-#define V3D_GEMM_GROUPM_DEFAULT 0
-#endif
+// Tile walk / tap order knobs (same-box A/B: tools/gemm_ab.sh, profiles/r02b_gemm_ab.txt):
+//   V3D_GEMM_GROUPM   -1 heuristic (default), 0 = row-major walk, n = groups of n tile rows.  Measured (TF/s, row-major -> 4 -> 8): GEGLU projection
+//                     N = 10240: 824 -> 877 -> 861, N = 5120: 714 -> 703 -> 737; temporal qkv N = 3840: 674 -> 738 -> 726; the feed-forward
+//                     out-projections +3 %; convolutions (N <= 5 tile columns) +-2 %.  Heuristic: 8 for >= 96 tile rows, else 4.
+//   V3D_GEMM_TAPINNER 1 = (k outer, tap inner) stage order.  It removes the 7-19x L2-miss re-reads of the K >= 640 convolutions but recomputes
+//                     the per-lane row offsets every 32-k step: 25-30 % SLOWER on every convolution (1044 -> 769 TF/s at 1920 -> 640) - the
+//                     loaders have no VALU to spare, the re-reads come from the Infinity Cache and are not what bounds these launches.  Off.
 #ifndef V3D_GEMM_TAPINNER_DEFAULT
 #define V3D_GEMM_TAPINNER_DEFAULT 0
 #endif
@@ -163,15 +166,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // the N = 10240 GEGLU projection fetched 20x its algorithmic bytes).  group_m > 1 walks down `group_m` tile rows before moving to the next
 // tile column, so the concurrent set is a group_m x (concurrency / group_m) patch that shares both operands; bijective for any mt, nt.
 __device__ __forceinline__ void tile_coords(const GP& p, int id, int& tm, int& tn) {
-    if (p.group_m <= 1) {
+    const int gm = p.group_m >= 0 ? p.group_m : (p.mt >= 96 ? 8 : 4);     // < 0: heuristic (see the knob comment at the top)
+    if (gm <= 1 || p.nt == 1) {
         tn = id % p.nt;
         tm = id / p.nt;
         return;
     }
-    const int width = p.group_m * p.nt;
+    const int width = gm * p.nt;
     const int gid = id / width;
-    const int first = gid * p.group_m;
-    const int gsz = (p.mt - first) < p.group_m ? (p.mt - first) : p.group_m;
+    const int first = gid * gm;
+    const int gsz = (p.mt - first) < gm ? (p.mt - first) : gm;
     const int r = id - gid * width;
     tn = r / gsz;
     tm = first + (r - tn * gsz);
@@ -1294,7 +1298,7 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
         static int gm = -2, ti = -2;
         if (gm == -2) { const char* e = getenv("V3D_GEMM_GROUPM"); gm = e ? atoi(e) : -1; }      // -1 = heuristic, 0 / 1 = row-major walk, n = groups of n tile rows
         if (ti == -2) { const char* e = getenv("V3D_GEMM_TAPINNER"); ti = e ? atoi(e) : -1; }
-        p.group_m = gm < 0 ? V3D_GEMM_GROUPM_DEFAULT : gm;
+        p.group_m = gm;        // (-1: resolved per launch from the tile-row count, see launch_group_m)
         p.tap_inner = ti < 0 ? V3D_GEMM_TAPINNER_DEFAULT : ti;
     }
     p.split_n = 1;
