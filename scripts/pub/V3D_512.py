@@ -101,7 +101,8 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
                max_guidance_scale: float = 3.5, sigma_max: float = None, ignore_alpha: bool = False, *, config=None,
                cond_frames: torch.Tensor = None, cond_frames_without_noise: torch.Tensor = None, image: torch.Tensor = None,
                synthetic: bool = False, clip_checkpoint_path: Optional[str] = None, clip_config=None,
-               height: int = 512, width: int = 512, model_channels: int = 320, vae_ch: int = 128):
+               height: int = 512, width: int = 512, model_channels: int = 320, vae_ch: int = 128,
+               ae_checkpoint_path: Optional[str] = None):
     """Returns (frames uint8 [T, H, W, 3] on the host, model).  Keyword arguments up to `ignore_alpha` are the reference's."""
     num_frames = 18 if num_frames is None else num_frames       # the reference reads it from the guider config (18)
     num_steps = 25 if num_steps is None else num_steps
@@ -121,10 +122,29 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
     F = 8
     h, w = height // F, width // F
     if cond_frames is None and image is not None:
-        # native VAE encode of the conditioning view (reference: `ae_model.encode(image)`, V3D_512.py:239): image [1,3,H,W] in [-1,1]
-        if checkpoint_path is None and synthetic and cached_model is None:
-            synth.init_module_fast(model.first_stage_model.encoder, seed=3)
-        cond_frames = model.first_stage_model.encode(image.to(device).float())
+        # native VAE encode of the conditioning view: image [1,3,H,W] in [-1,1].  The reference encodes with a SEPARATE autoencoder whose
+        # weights are svd_xt.safetensors' first_stage_model.* (`ae_model`, V3D_512.py:155-163,239), not with V3D_512.ckpt's first stage:
+        # `ae_checkpoint_path` (default: the CLIP checkpoint, which is that same svd_xt file) reproduces that; without it the model's own
+        # first stage is used and a warning says so.
+        ae_model = getattr(model, "_v3d_ae_model", None)
+        ae_ckpt = ae_checkpoint_path or clip_checkpoint_path
+        if ae_model is None and ae_ckpt is not None and ae_ckpt.endswith("safetensors"):
+            from safetensors.torch import load_file
+            fsd = {k[len("first_stage_model."):]: v for k, v in load_file(ae_ckpt).items() if k.startswith("first_stage_model.")}
+            if fsd:
+                fcfg = cfg["model"]["params"]["first_stage_config"] if "model" in cfg else cfg["params"]["first_stage_config"]
+                ae_model = instantiate_from_config(fcfg).eval()
+                missing, unexpected = ae_model.load_state_dict(fsd, strict=False)
+                print(f"conditioning autoencoder restored from {ae_ckpt} ({len(missing)} missing / {len(unexpected)} unexpected keys)")
+                model._v3d_ae_model = ae_model = ae_model.to(device)
+        if ae_model is None:
+            ae_model = model.first_stage_model
+            if checkpoint_path is not None:
+                print("warning: the conditioning view is encoded with the model's own first stage; the reference uses svd_xt.safetensors' "
+                      "first_stage_model.* - pass --ae_checkpoint_path (or --clip_checkpoint_path) to match it")
+            elif synthetic and cached_model is None:
+                synth.init_module_fast(model.first_stage_model.encoder, seed=3)
+        cond_frames = ae_model.encode(image.to(device).float())
     if cond_frames_without_noise is None and image is not None:
         # native OpenCLIP image embedding (reference: configs/embedder/clip_image.yaml -> `clip_model(image)`, V3D_512.py:146-153,238);
         # weights = the checkpoint's conditioner.embedders.0.* (svd_xt.safetensors), random-initialised under --synthetic
@@ -200,9 +220,20 @@ def main():
     ap.add_argument("--sigma_max", type=float, default=None)
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--clip_checkpoint_path", default=None, help="svd_xt.safetensors (conditioner.embedders.0.* = the OpenCLIP image tower)")
+    ap.add_argument("--ae_checkpoint_path", default=None, help="svd_xt.safetensors (first_stage_model.* = the autoencoder the reference encodes the "
+                                                               "conditioning view with); defaults to --clip_checkpoint_path")
+    ap.add_argument("--border_ratio", type=float, default=0.3, help="reference argument of its rembg / kiui recentering step, which this build does "
+                                                                    "not run: the input must already be a prepared (matted, centred) RGB view")
+    ap.add_argument("--ignore_alpha", action="store_true")
     a = ap.parse_args()
+    if not os.path.isfile(a.input_path) and not a.synthetic:
+        raise SystemExit(f"input image {a.input_path} not found (pass --synthetic to run on synthetic conditioning)")
     image = None
     if os.path.isfile(a.input_path):
+        from PIL import Image as _Image
+        if _Image.open(a.input_path).mode in ("RGBA", "LA") and not a.ignore_alpha:
+            print("warning: the input has an alpha channel; the reference composites it on white after rembg / recentering (border_ratio "
+                  f"{a.border_ratio}) - this build takes the RGB channels as they are")
         # plain load + resize to 512 x 512 -> [-1, 1]; the reference's matting / recentering (rembg, kiui) stays outside this build
         from PIL import Image
         import numpy as np
@@ -211,7 +242,8 @@ def main():
     frames, _ = sample_one(a.input_path, a.checkpoint_path, a.num_frames, a.num_steps, a.fps_id, a.motion_bucket_id, a.cond_aug, a.seed,
                            a.decoding_t, a.device, a.output_folder, save=a.save, min_guidance_scale=a.min_guidance_scale,
                            max_guidance_scale=a.max_guidance_scale, sigma_max=a.sigma_max, config=a.config, synthetic=a.synthetic, image=image,
-                           clip_checkpoint_path=a.clip_checkpoint_path)
+                           clip_checkpoint_path=a.clip_checkpoint_path, ae_checkpoint_path=a.ae_checkpoint_path, border_ratio=a.border_ratio,
+                           ignore_alpha=a.ignore_alpha)
     print("frames", frames.shape, frames.dtype, "mean", float(frames.mean()))
 
 

@@ -87,7 +87,12 @@ def test_entry_script_from_an_image_runs_the_native_front_end(tmp_path):
     torch.manual_seed(0)
     donor = entry.instantiate_from_config(clip_cfg)
     ck = str(tmp_path / "svd_xt_like.safetensors")
-    save_file({"conditioner.embedders.0." + k: v.contiguous() for k, v in donor.state_dict().items()}, ck)
+    # svd_xt.safetensors also carries first_stage_model.*: the autoencoder the reference encodes the conditioning view with (V3D_512.py:155-163)
+    fcfg = configs.v3d_512_config(model_channels=64, vae_ch=32)["model"]["params"]["first_stage_config"]
+    ae_donor = entry.instantiate_from_config(fcfg)
+    ae_sd = synth.seeded_state_dict(ae_donor, 99)
+    save_file({**{"conditioner.embedders.0." + k: v.contiguous() for k, v in donor.state_dict().items()},
+               **{"first_stage_model." + k: v.contiguous() for k, v in ae_sd.items()}}, ck)
     image = torch.rand(1, 3, 128, 128) * 2 - 1
     with use_backend(EmulOps("cpu", exact=True)):
         frames, model = entry.sample_one(num_frames=3, num_steps=2, device="cpu", synthetic=True, height=128, width=128, model_channels=64,
@@ -95,6 +100,8 @@ def test_entry_script_from_an_image_runs_the_native_front_end(tmp_path):
         want = donor(image)
         got = model._v3d_clip_model(image)
     assert frames.shape == (3, 128, 128, 3)
+    ae = model._v3d_ae_model                     # the separate conditioning autoencoder, restored from the svd_xt-like file
+    assert ae is not model.first_stage_model and all(torch.equal(v, ae_sd[k]) for k, v in ae.state_dict().items())
     assert got.shape == (1, 1, 1024)
     torch.testing.assert_close(got, want)
 
