@@ -194,7 +194,7 @@ class _Timed:
             self._wrap("quant_fp8_tiles", lambda x, n_img, S: ("quant_fp8", 0.0, x.shape[0] * x.shape[1] * 3))
             self._wrap("quant_fp8_slab", lambda vT, heads: ("quant_fp8", 0.0, vT.numel() * 5))
         if hasattr(self.ops, "attn_vae"):
-            self._wrap("attn_vae", lambda q, k, v, out, n_img, S, C, scale: ("attn_vae_d512", 4.0 * n_img * S * S * C, 4 * n_img * S * C * 2))
+            self._wrap("attn_vae", lambda q, k, vT, bias, out, n_img, S, C, scale: ("attn_vae_d512", 4.0 * n_img * S * S * C, 4 * n_img * S * C * 2))
         return self
 
     def __exit__(self, *exc):
