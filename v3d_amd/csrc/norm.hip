@@ -17,11 +17,11 @@ struct GNGeom {
     int NV;    // vector columns per thread
 };
 
-__host__ __device__ inline GNGeom gn_geom(long long C, int nthreads = 256) {
+__host__ __device__ inline GNGeom gn_geom(long long C) {
     GNGeom g;
     g.VC = (int)(C / 8);
-    g.TPR = g.VC < 256 ? g.VC : 256;     // (at most 256 threads per row in either block size: NV covers the rest)
-    g.RPP = nthreads / g.TPR;
+    g.TPR = g.VC < 256 ? g.VC : 256;
+    g.RPP = 256 / g.TPR;
     g.NV = (g.VC + g.TPR - 1) / g.TPR;
     return g;
 }
@@ -40,10 +40,8 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
 // NV (vector columns per thread) is a template parameter and the per-channel LDS partials are sized by C (dynamic shared
 // memory): the first version carried the dead second column through every load / fma and declared 32 KiB of LDS, which
 // capped a CU at 5 blocks - 56 us for the 94 MB 64x64 level where the read+write gn_apply takes 36 us.
-// NT threads per block: 512 for the large levels - the block count is pinned by the atomics (above), so bytes in flight per CU come from
-// threads per block: 8 waves x 8 rows x 16 B per lane instead of 4 waves (94 MB level: 28 -> see profiles/r02*_op_times).
-template <int NV, int UR, int NT>
-__global__ __launch_bounds__(NT) void gn_stats_kernel(const bf16_t* __restrict__ x1, long long C1,
+template <int NV, int UR>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x1, long long C1,
                                                        const bf16_t* __restrict__ x2, long long C2,
                                                        float* __restrict__ stats, long long S, int groups,
                                                        long long imgs_per_stat, long long rpb) {
@@ -51,14 +49,14 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const bf16_t* __restrict__
     const long long C = C1 + C2;
     float* sh_s = gn_sh;
     float* sh_q = gn_sh + C;
-    const GNGeom g = gn_geom(C, NT);
+    const GNGeom g = gn_geom(C);
     const int tid = threadIdx.x;
     const long long img = blockIdx.y;
     const long long r_begin = (long long)blockIdx.x * rpb;
     long long r_end = r_begin + rpb;
     if (r_end > S) r_end = S;
 
-    for (int c = tid; c < 2 * C; c += NT) gn_sh[c] = 0.f;
+    for (int c = tid; c < 2 * C; c += 256) gn_sh[c] = 0.f;
     __syncthreads();
 
     const int trow = tid / g.TPR;
@@ -352,13 +350,7 @@ extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, i
     int rc = gn_check("v3d_groupnorm_stats", x1, C1, x2, C2, n_img, S, groups);
     if (rc) return rc;
     V3D_REQUIRE(stats != nullptr && imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_stats: bad stats/imgs_per_stat");
-    static int nt512 = -1;
-    if (nt512 < 0) {
-        const char* e = getenv("V3D_GN_NT512");    // A/B knob: 0 = 256-thread blocks everywhere
-        nt512 = e ? atoi(e) : 1;
-    }
-    const bool big = nt512 && n_img * S * (C1 + C2) * 2 >= (24ll << 20) && (C1 + C2) <= 2048;
-    const GNGeom g = gn_geom(C1 + C2, big ? 512 : 256);
+    const GNGeom g = gn_geom(C1 + C2);
     long long chunks, rpb;
     static long long target = -1;
     if (target < 0) {
@@ -372,17 +364,12 @@ extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, i
     gn_grid(n_img, S, g, chunks, rpb, target > 0 ? target : (bytes > (256ll << 20) ? 768 : 256));
     const size_t shmem = (size_t)(C1 + C2) * 2 * sizeof(float);
     const dim3 grid((unsigned)chunks, (unsigned)n_img);
-#define V3D_GNS_LAUNCH(NV_, UR_, NT_)                                                                                                   \
-    hipLaunchKernelGGL((gn_stats_kernel<NV_, UR_, NT_>), grid, dim3(NT_), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1, \
-                       (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups, (long long)imgs_per_stat, rpb)
-    if (g.NV == 1) {
-        if (big) V3D_GNS_LAUNCH(1, 8, 512);
-        else V3D_GNS_LAUNCH(1, 8, 256);
-    } else {
-        if (big) V3D_GNS_LAUNCH(2, 4, 512);
-        else V3D_GNS_LAUNCH(2, 4, 256);
-    }
-#undef V3D_GNS_LAUNCH
+    if (g.NV == 1)
+        hipLaunchKernelGGL((gn_stats_kernel<1, 8>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                           (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups, (long long)imgs_per_stat, rpb);
+    else
+        hipLaunchKernelGGL((gn_stats_kernel<2, 4>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                           (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups, (long long)imgs_per_stat, rpb);
     return v3d_check_launch("v3d_groupnorm_stats");
 }
 
