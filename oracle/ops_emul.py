@@ -302,6 +302,18 @@ class EmulOps(OpsBase):
         out.copy_(y.to(out.dtype))
         return out
 
+    LN_PROJ_WIDTHS = (320,)
+
+    def ln_proj(self, x, gamma, beta, eps, wp, n_rm, S):
+        M, C = x.shape
+        N = wp.shape[0]
+        w = self._ff_untile(wp, N, C, 64, C).float()                        # undo the LDS-DMA piece order
+        xn = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), eps).to(self.act_dtype).float()
+        y = xn @ w.t()
+        out = y[:, :n_rm].to(self.act_dtype).contiguous() if n_rm else None
+        outT = y[:, n_rm:].reshape(M // S, S, N - n_rm).permute(0, 2, 1).to(self.act_dtype).contiguous() if n_rm < N else None
+        return out, outT
+
     def clip_preprocess(self, img, size, patch, antialias, mean, std, kpad):
         """kornia.geometry.resize(bicubic, align_corners=True, antialias) restated with torch ops + normalise + patch unfold."""
         B, _, H, W = img.shape

@@ -185,6 +185,25 @@ def case_attn_vae(hip, emu, dev, *, n_img, S, C=512, seed=0, spike=False, bias=T
     return compare(o_h, o_e)
 
 
+def case_ln_proj(hip, emu, dev, *, M, N, n_rm, S, seed=0):
+    """v3d_ln_proj (LayerNorm + q | k | v projection, row-major and transposed outputs) against layer_norm -> bf16 -> matmul."""
+    from v3d_amd.engine.packing import ln_proj_pack
+    g = torch.Generator().manual_seed(seed)
+    C = 320
+    x = (_rand(g, (M, C + 8), F32, 1.5, dev) + 0.3).to(BF)[:, :C]          # strided rows, non-zero mean
+    w = _rand(g, (N, C), scale=1 / math.sqrt(C), device=dev)
+    gamma, beta = _rand(g, (C,), F32, 0.3, dev) + 1.0, _rand(g, (C,), F32, 0.3, dev)
+    wp = ln_proj_pack(w)
+    o_h, t_h = hip.ln_proj(x, gamma, beta, 1e-5, wp, n_rm, S)
+    o_e, t_e = emu.ln_proj(x, gamma, beta, 1e-5, wp, n_rm, S)
+    rel, cos = 0.0, 1.0
+    for a, b in ((o_h, o_e), (t_h, t_e)):
+        if a is not None:
+            r, c = compare(a, b)
+            rel, cos = max(rel, r), min(cos, c)
+    return rel, cos
+
+
 def case_attn_fp8(hip, emu, dev, *, n_img, S, heads, seed=0, what="attn"):
     """fp8 attention chain.  what="quant": the two quantisation kernels against torch.float8_e4m3fn (bytes may differ by one code where a value
     sits on a rounding boundary after the scale division: compared after dequantisation); what="attn": v3d_attn_spatial_fp8 against exact
@@ -361,6 +380,10 @@ def all_cases(full: bool = True):
         ("convt3_split_halo_mid", case_convt3_split_halo, dict(B=2, T=3, S=16, N=64, K=64), TOL_BF16),
         ("convt3_split_halo_first", case_convt3_split_halo, dict(B=2, T=2, S=40, N=72, K=64, first=True), TOL_BF16),
         ("convt3_split_halo_last_v3", case_convt3_split_halo, dict(B=2, T=9, S=256, N=320, K=320, last=True), TOL_BF16),
+        ("ln_proj_qkv_spatial", case_ln_proj, dict(M=3 * 256, N=960, n_rm=640, S=256), TOL_BF16),
+        ("ln_proj_qkv_temporal", case_ln_proj, dict(M=128 * 5, N=960, n_rm=960, S=128, seed=1), TOL_BF16),
+        ("ln_proj_all_transposed", case_ln_proj, dict(M=2 * 128, N=128, n_rm=0, S=128, seed=2), TOL_BF16),
+        ("ln_proj_many_blocks", case_ln_proj, dict(M=128 * 700, N=960, n_rm=640, S=128 * 50, seed=3), TOL_BF16),
         ("fp8_quant_S256", case_attn_fp8, dict(n_img=2, S=256, heads=2, what="quant"), 7e-2),
         ("fp8_quant_S144_ragged", case_attn_fp8, dict(n_img=2, S=144, heads=1, what="quant"), 7e-2),
         ("fp8_attn_S256", case_attn_fp8, dict(n_img=2, S=256, heads=2), 6e-2),

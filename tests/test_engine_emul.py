@@ -147,3 +147,26 @@ def test_unet_rejects_multi_token_context_and_missing_indicator():
             net(x8, ts, context=torch.cat([ctx, ctx], dim=1), y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
         with pytest.raises(AssertionError, match="image_only_indicator is required"):
             net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=None)
+
+
+def test_ln_proj_path_equals_unfused_path(monkeypatch):
+    """The 64x64-level shortcut (v3d_ln_proj: LayerNorm + q | k | v projection in one kernel, V^T written directly) against the
+    LayerNorm -> GEMM -> swapped batched GEMM sequence it replaces, on a one-level width-320 network with exact-fp32 emulated kernels."""
+    from v3d_amd import synth
+    from v3d_amd.sgm.modules.diffusionmodules.video_model import VideoUNet
+    cfg = dict(synth.unet_config(320), channel_mult=[1], num_res_blocks=1, attention_resolutions=[1])
+    T, H, W = 2, 8, 16                                   # 128 tokens per image: the kernel's block granularity
+    g = torch.Generator().manual_seed(5)
+    n = 2 * T
+    x8, ts = torch.randn(n, 8, H, W, generator=g), torch.randn(n, generator=g)
+    ctx, y = torch.randn(n, 1, 1024, generator=g), torch.randn(n, 768, generator=g)
+    with use_backend(EmulOps("cpu", exact=True)):
+        net = VideoUNet(**cfg).eval()
+        net.load_state_dict(synth.seeded_state_dict(net, 21))
+        assert net.packed().input_stages[1][1][1].s_wqkv_fused is not None
+        monkeypatch.setenv("V3D_LN_PROJ", "1")
+        a = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+        monkeypatch.setenv("V3D_LN_PROJ", "0")
+        b = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+    rel, cos = rel_cos(a, b)
+    assert rel <= 1e-5 and cos >= 0.999999, (rel, cos)

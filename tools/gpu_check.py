@@ -164,6 +164,29 @@ def bench(hip):
         out.append(dict(name=name, ms=ms, gbps=byt / ms / 1e6))
         print(f"{name:34s} M={M} C={C}  {ms:8.3f} ms  {byt / ms / 1e6:8.1f} GB/s", flush=True)
 
+    def lnproj_case(name, M, N, n_rm, S):
+        if not want(name):
+            return
+        from v3d_amd.engine.packing import ln_proj_pack
+        C = 320
+        x = torch.randn(M, C, device=dev).to(BF)
+        w = (torch.randn(N, C, device=dev) / C ** 0.5).to(BF)
+        wp = ln_proj_pack(w)
+        ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        ms = timeit(lambda: hip.ln_proj(x, ga, be, 1e-5, wp, n_rm, S))
+        n1 = torch.empty_like(x)
+        o2 = torch.empty(M, N, dtype=BF, device=dev)
+
+        def unfused():
+            hip.layernorm(x, ga, be, n1, 1e-5)
+            hip.gemm(GemmCall(A=n1, W=w, out=o2, M=M, N=N, K=C))
+        ms2 = timeit(unfused)
+        out.append(dict(name=name, ms=ms, unfused_ms=ms2, tflops=2.0 * M * N * C / ms / 1e9))
+        print(f"{name:34s} M={M} N={N} n_rm={n_rm}  {ms * 1e3:8.1f} us fused   vs {ms2 * 1e3:8.1f} us layernorm + one v3d_gemm (N = {N})", flush=True)
+
+    lnproj_case("lnproj_L0_spatial_qkv", 36 * 4096, 960, 640, 4096)
+    lnproj_case("lnproj_L0_temporal_qkv", 36 * 4096, 960, 960, 4096)
+
     def vattn_case(name, n_img, S, C=512):
         if not want(name):
             return

@@ -59,12 +59,19 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
 
     # ---- spatial BasicTransformerBlock (attention.py:556-577) ----
     ga, be, eps = p.s_norm1
-    n1 = ops.empty((n * S, C), ops.act_dtype, x.device)
-    ops.layernorm(x, ga, be, n1, eps)
-    qk = ops.linear(n1, p.s_wqk)
-    # V^T[img] = Wv @ LN(x)[img]^T directly out of the projection: keys contiguous for the P.V MFMA, no transpose
-    vT = ops.empty((n, C, S), ops.act_dtype, x.device)
-    ops.gemm(GemmCall(A=p.s_wv, W=n1.view(n, S, C), out=vT, M=C, N=S, K=C, batch=n))
+    # the 64x64 level: LayerNorm + q | k | v projection in ONE kernel (token rows normalised in registers, V^T written directly)
+    ln_proj = (os.environ.get("V3D_LN_PROJ", "1") not in ("", "0") and p.s_wqkv_fused is not None and C in getattr(ops, "LN_PROJ_WIDTHS", ())
+               and S % 128 == 0)
+    n1 = None
+    if ln_proj:
+        qk, vT = ops.ln_proj(x, ga, be, eps, p.s_wqkv_fused, 2 * C, S)
+    else:
+        n1 = ops.empty((n * S, C), ops.act_dtype, x.device)
+        ops.layernorm(x, ga, be, n1, eps)
+        qk = ops.linear(n1, p.s_wqk)
+        # V^T[img] = Wv @ LN(x)[img]^T directly out of the projection: keys contiguous for the P.V MFMA, no transpose
+        vT = ops.empty((n, C, S), ops.act_dtype, x.device)
+        ops.gemm(GemmCall(A=p.s_wv, W=n1.view(n, S, C), out=vT, M=C, N=S, K=C, batch=n))
     a = ops.empty((n * S, C), ops.act_dtype, x.device)
     if os.environ.get("V3D_ATTN_FP8", "0") not in ("", "0") and hasattr(ops, "attn_spatial_fp8") and S % 16 == 0:
         # scene-config variant (BASELINE.json configs[4]): e4m3 q | k tiles and V^T slabs, QK^T and P.V on the K = 64 fp8 MFMA
@@ -89,12 +96,18 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     ops.layernorm(x_s, ga, be, nin, eps, add=table, add_rpg=S, add_ld=C, xsum_out=x_mix)
     x_t = feed_forward(ops, nin, p.t_ff_in, res1=x_mix)
     ga, be, eps = p.t_norm1
-    ops.layernorm(x_t, ga, be, n1, eps)
     ta = ops.empty((B, T, S, C), ops.act_dtype, x.device)
-    if sh is None:
+    if sh is None and ln_proj:
+        qkv = ops.ln_proj(x_t, ga, be, eps, p.t_wqkv_fused, 3 * C, S)[0].view(B, T, S, 3 * C)
+        ops.attn_temporal(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], ta, p.heads, 0.125)
+    elif sh is None:
+        n1 = ops.empty((n * S, C), ops.act_dtype, x.device) if n1 is None else n1
+        ops.layernorm(x_t, ga, be, n1, eps)
         qkv = ops.linear(n1, p.t_wqkv).view(B, T, S, 3 * C)
         ops.attn_temporal(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], ta, p.heads, 0.125)
     else:
+        n1 = ops.empty((n * S, C), ops.act_dtype, x.device) if n1 is None else n1
+        ops.layernorm(x_t, ga, be, n1, eps)
         # frame-sharded: to_k | to_v first, their all-gather along frames goes out at once (asynchronously: RCCL's own stream on
         # the box) and the to_q GEMM runs while it is in flight
         kv_loc = ops.linear(n1, p.t_wqkv[C:]).view(B, T, S, 2 * C)
