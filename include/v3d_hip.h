@@ -124,14 +124,15 @@ int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const float* b1, c
                  v3d_stream_t stream);
 /* LayerNorm + q | k | v projection of a transformer block in one kernel (ABI 3; C = 320, the 64x64 level).  Reference:
  * BasicTransformerBlock / VideoTransformerBlock x -> norm1(x) -> attn1.to_q / to_k / to_v (sgm/modules/attention.py:556-563,286-290;
- * sgm/modules/video_attention.py:122-125; the three Linears have no bias).  xn = bf16(LayerNorm(x[m], gamma, beta, eps)) stays in registers;
- *   out[m][n]            = sum_k xn[m][k] W[n][k]                        for n <  n_rm   (row-major, row stride ldo)
- *   outT[m / S][n - n_rm][m % S] = sum_k xn[m][k] W[n][k]                for n >= n_rm   (V^T layout of v3d_attn_spatial: keys contiguous)
- * Wp = the concatenated [N][C] weight (q ; k ; v) stored in the kernel's LDS-DMA order (v3d_amd/engine/packing.py ff_dma_tile_index(N, C, 64, C):
- * slabs of 64 rows, 1-KiB pieces of 16 rows x 32 columns ordered (column block, row block), 16-byte unit 4 r + p of a piece = columns
- * 8 (p ^ swz(r)) .. of row r, swz(r) = {0,2,3,1}[(r >> 2) & 3]).  M % 128 == 0, N % 64 == 0, n_rm % 64 == 0; S % 128 == 0 when n_rm < N. */
-int v3d_ln_proj(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* Wp, void* out, int64_t ldo,
-                void* outT, int64_t M, int32_t C, int32_t N, int32_t n_rm, int64_t S, v3d_stream_t stream);
+ * sgm/modules/video_attention.py:122-125; the three Linears have no bias).  The LayerNorm affine is folded through the projection at pack time
+ * (W' = W diag(gamma), bias = W beta: v3d_amd/engine/packing.py ln_proj_pack); xh = bf16((x[m] - mean) * rstd) stays in registers;
+ *   out[m][n]                    = sum_k xh[m][k] W'[n][k] + bias[n]     for n <  n_rm   (row-major, row stride ldo)
+ *   outT[m / S][n - n_rm][m % S] = sum_k xh[m][k] W'[n][k] + bias[n]     for n >= n_rm   (V^T layout of v3d_attn_spatial: keys contiguous)
+ * Wp = the concatenated [N][C] weight (q ; k ; v, gamma folded in) stored in the kernel's LDS-DMA order (ff_dma_tile_index(N, C, 64, C): slabs of
+ * 64 rows, 1-KiB pieces of 16 rows x 32 columns ordered (column block, row block), 16-byte unit 4 r + p of a piece = columns 8 (p ^ swz(r)) .. of
+ * row r, swz(r) = {0,2,3,1}[(r >> 2) & 3]).  M % 128 == 0, N % 64 == 0 (<= 1024), n_rm % 64 == 0; S % 128 == 0 when n_rm < N. */
+int v3d_ln_proj(const void* x, int64_t ldx, float eps, const void* Wp, const float* bias, void* out, int64_t ldo, void* outT,
+                int64_t M, int32_t C, int32_t N, int32_t n_rm, int64_t S, v3d_stream_t stream);
 /* sizeof(v3d_gemm_args) as compiled into the library: lets a foreign-language binding verify its struct mirror */
 int v3d_sizeof_gemm_args(void);
 

@@ -304,12 +304,12 @@ class EmulOps(OpsBase):
 
     LN_PROJ_WIDTHS = (320,)
 
-    def ln_proj(self, x, gamma, beta, eps, wp, n_rm, S):
+    def ln_proj(self, x, eps, wp, bias, n_rm, S):
         M, C = x.shape
         N = wp.shape[0]
         w = self._ff_untile(wp, N, C, 64, C).float()                        # undo the LDS-DMA piece order
-        xn = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), eps).to(self.act_dtype).float()
-        y = xn @ w.t()
+        xh = F.layer_norm(x.float(), (C,), None, None, eps).to(self.act_dtype).float()    # affine folded into w / bias at pack time
+        y = xh @ w.t() + bias.float()[None, :]
         out = y[:, :n_rm].to(self.act_dtype).contiguous() if n_rm else None
         outT = y[:, n_rm:].reshape(M // S, S, N - n_rm).permute(0, 2, 1).to(self.act_dtype).contiguous() if n_rm < N else None
         return out, outT

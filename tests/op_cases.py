@@ -193,9 +193,9 @@ def case_ln_proj(hip, emu, dev, *, M, N, n_rm, S, seed=0):
     x = (_rand(g, (M, C + 8), F32, 1.5, dev) + 0.3).to(BF)[:, :C]          # strided rows, non-zero mean
     w = _rand(g, (N, C), scale=1 / math.sqrt(C), device=dev)
     gamma, beta = _rand(g, (C,), F32, 0.3, dev) + 1.0, _rand(g, (C,), F32, 0.3, dev)
-    wp = ln_proj_pack(w)
-    o_h, t_h = hip.ln_proj(x, gamma, beta, 1e-5, wp, n_rm, S)
-    o_e, t_e = emu.ln_proj(x, gamma, beta, 1e-5, wp, n_rm, S)
+    wp, bias = ln_proj_pack(w, gamma, beta)
+    o_h, t_h = hip.ln_proj(x, 1e-5, wp, bias, n_rm, S)
+    o_e, t_e = emu.ln_proj(x, 1e-5, wp, bias, n_rm, S)
     rel, cos = 0.0, 1.0
     for a, b in ((o_h, o_e), (t_h, t_e)):
         if a is not None:
@@ -384,6 +384,7 @@ def all_cases(full: bool = True):
         ("ln_proj_qkv_temporal", case_ln_proj, dict(M=128 * 5, N=960, n_rm=960, S=128, seed=1), TOL_BF16),
         ("ln_proj_all_transposed", case_ln_proj, dict(M=2 * 128, N=128, n_rm=0, S=128, seed=2), TOL_BF16),
         ("ln_proj_many_blocks", case_ln_proj, dict(M=128 * 700, N=960, n_rm=640, S=128 * 50, seed=3), TOL_BF16),
+        ("ln_proj_8w_rowmajor", case_ln_proj, dict(M=256 * 300, N=960, n_rm=960, S=256, seed=4), TOL_BF16),
         ("fp8_quant_S256", case_attn_fp8, dict(n_img=2, S=256, heads=2, what="quant"), 7e-2),
         ("fp8_quant_S144_ragged", case_attn_fp8, dict(n_img=2, S=144, heads=1, what="quant"), 7e-2),
         ("fp8_attn_S256", case_attn_fp8, dict(n_img=2, S=256, heads=2), 6e-2),

@@ -171,9 +171,9 @@ def bench(hip):
         C = 320
         x = torch.randn(M, C, device=dev).to(BF)
         w = (torch.randn(N, C, device=dev) / C ** 0.5).to(BF)
-        wp = ln_proj_pack(w)
+        wp, pbias = ln_proj_pack(w, torch.ones(C, device=dev), torch.zeros(C, device=dev))
         ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-        ms = timeit(lambda: hip.ln_proj(x, ga, be, 1e-5, wp, n_rm, S))
+        ms = timeit(lambda: hip.ln_proj(x, 1e-5, wp, pbias, n_rm, S))
         n1 = torch.empty_like(x)
         o2 = torch.empty(M, N, dtype=BF, device=dev)
 

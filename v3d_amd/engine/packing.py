@@ -162,10 +162,13 @@ def ff_fused_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
     return (_bf(w1p.reshape(-1)[t1].reshape(2 * hidden, C)), _f(b1[ro]), _bf(w2p.reshape(-1)[t2].reshape(C, hidden)))
 
 
-def ln_proj_pack(w: torch.Tensor) -> torch.Tensor:
-    """[N, C] concatenated q ; k ; v weight -> the LDS-DMA piece order of v3d_ln_proj (slabs of 64 rows, see ff_dma_tile_index)."""
+def ln_proj_pack(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """[N, C] concatenated q ; k ; v weight + the LayerNorm affine in front of it -> (Wp, bias) of v3d_ln_proj: LN(x) W^T = xh (W diag(gamma))^T + W beta
+    with xh = (x - mean) * rstd, Wp in the kernel's LDS-DMA piece order (slabs of 64 rows, see ff_dma_tile_index), bias fp32."""
     N, C = w.shape
-    return _bf(w.detach().reshape(-1)[ff_dma_tile_index(N, C, 64, C).to(w.device)].reshape(N, C))
+    wf = w.detach().float()
+    wg = wf * gamma.detach().float()[None, :]
+    return (_bf(wg.reshape(-1)[ff_dma_tile_index(N, C, 64, C).to(w.device)].reshape(N, C)), _f(wf @ beta.detach().float()))
 
 
 @dataclass
@@ -186,8 +189,8 @@ class SVTPack:
     t_ff_in: FFPack = None
     t_norm1: tuple = None
     t_wqkv: torch.Tensor = None
-    s_wqkv_fused: Optional[torch.Tensor] = None     # C = 320 only: DMA-tiled [3C, C] for v3d_ln_proj
-    t_wqkv_fused: Optional[torch.Tensor] = None
+    s_wqkv_fused: Optional[tuple] = None     # C = 320 only: (DMA-tiled [3C, C] weight with norm1's gamma folded in, bias W beta) for v3d_ln_proj
+    t_wqkv_fused: Optional[tuple] = None
     t_wo: tuple = None
     t_ctx_off: int = 0
     t_norm3: tuple = None
@@ -296,8 +299,8 @@ def pack_svt(st, col: _Collector) -> SVTPack:
     p.s_wqk = _bf(torch.cat([blk.attn1.to_q.weight.detach(), blk.attn1.to_k.weight.detach()], dim=0))
     p.s_wv = _bf(blk.attn1.to_v.weight)
     if C == 320:     # the 64x64 level: LayerNorm + q | k | v projection in one kernel (v3d_ln_proj)
-        p.s_wqkv_fused = ln_proj_pack(torch.cat([blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight], dim=0))
-        p.t_wqkv_fused = ln_proj_pack(torch.cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dim=0))
+        p.s_wqkv_fused = ln_proj_pack(torch.cat([blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight], dim=0), blk.norm1.weight, blk.norm1.bias)
+        p.t_wqkv_fused = ln_proj_pack(torch.cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dim=0), tb.norm1.weight, tb.norm1.bias)
     p.s_wo = pack_linear(blk.attn1.to_out[0])
     p.s_ctx_off = col.add_ctx(blk.attn2)
     p.s_norm3 = pack_norm(blk.norm3)

@@ -64,7 +64,7 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
                and S % 128 == 0)
     n1 = None
     if ln_proj:
-        qk, vT = ops.ln_proj(x, ga, be, eps, p.s_wqkv_fused, 2 * C, S)
+        qk, vT = ops.ln_proj(x, eps, p.s_wqkv_fused[0], p.s_wqkv_fused[1], 2 * C, S)
     else:
         n1 = ops.empty((n * S, C), ops.act_dtype, x.device)
         ops.layernorm(x, ga, be, n1, eps)
@@ -98,7 +98,7 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     ga, be, eps = p.t_norm1
     ta = ops.empty((B, T, S, C), ops.act_dtype, x.device)
     if sh is None and ln_proj:
-        qkv = ops.ln_proj(x_t, ga, be, eps, p.t_wqkv_fused, 3 * C, S)[0].view(B, T, S, 3 * C)
+        qkv = ops.ln_proj(x_t, eps, p.t_wqkv_fused[0], p.t_wqkv_fused[1], 3 * C, S)[0].view(B, T, S, 3 * C)
         ops.attn_temporal(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], ta, p.heads, 0.125)
     elif sh is None:
         n1 = ops.empty((n * S, C), ops.act_dtype, x.device) if n1 is None else n1

@@ -50,7 +50,7 @@ SIGNATURES = {
     "v3d_sizeof_gemm_args": (c_i32, []),
     "v3d_ff_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32, c_f32,
                              c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
-    "v3d_ln_proj": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp]),
+    "v3d_ln_proj": (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp]),
     "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i64,
                                     c_f64, c_f32, c_i32, c_vp]),
@@ -420,16 +420,16 @@ class HipOps(OpsBase):
 
     LN_PROJ_WIDTHS = (320,)
 
-    def ln_proj(self, x, gamma, beta, eps, wp, n_rm, S):
-        """LayerNorm(x) @ wp^T for the concatenated q | k | v weight (DMA-tiled, packing.ln_proj_pack): returns (out [M, n_rm] or None,
-        outT [M / S, N - n_rm, S] or None)."""
+    def ln_proj(self, x, eps, wp, bias, n_rm, S):
+        """(x - mean) * rstd per row, then @ wp^T + bias for the concatenated q | k | v weight with the LayerNorm affine folded in (DMA-tiled,
+        packing.ln_proj_pack): returns (out [M, n_rm] or None, outT [M / S, N - n_rm, S] or None)."""
         bf, f32 = torch.bfloat16, torch.float32
-        self._req(x, bf, "ln_proj.x"); self._req_c(wp, bf, "ln_proj.w"); self._req_c(gamma, f32, "ln_proj.gamma"); self._req_c(beta, f32, "ln_proj.beta")
+        self._req(x, bf, "ln_proj.x"); self._req_c(wp, bf, "ln_proj.w"); self._req_c(bias, f32, "ln_proj.bias")
         M, Cc = x.shape
         N = wp.shape[0]
         out = self.empty((M, n_rm), bf, x.device) if n_rm else None
         outT = self.empty((M // S, N - n_rm, S), bf, x.device) if n_rm < N else None
-        self._check(self.lib.v3d_ln_proj(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), float(eps), wp.data_ptr(), _ptr(out),
+        self._check(self.lib.v3d_ln_proj(x.data_ptr(), x.stride(0), float(eps), wp.data_ptr(), bias.data_ptr(), _ptr(out),
                                          n_rm if out is not None else 0, _ptr(outT), M, Cc, N, n_rm, S, self._stream()), "v3d_ln_proj")
         return out, outT
 
