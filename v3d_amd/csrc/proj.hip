@@ -46,22 +46,35 @@ __device__ __forceinline__ int pj_swz(int row) { return (0x78 >> (((row >> 2) & 
 
 __device__ unsigned long long g_pj_dbg[8 * 32 * 8];   // timeline build (V3D_LNPROJ_TIMELINE=1): [wave][stream slab 16..47][stamp]
 
-// NW waves of 32 rows share every weight slab.  NW = 8 (two waves per SIMD, 256 rows per block) is the default: with one wave per SIMD every
-// VMEM issue stall of a slab (LDS-DMA pieces ~70 cycles each, 16-byte stores ~375 each with the queue full of DMA traffic) starved the matrix
-// pipe - 5500 cycles per slab against 1280 of MFMA work (tools/lnproj_timeline.py) - the second wave runs its MFMAs in those gaps, and the weight
-// stream per row halves.
-template <int C, int NW, bool DBG = false>
+// NW waves of RF x 32 rows share every weight slab (block = NW * RF * 32 rows):
+//   <8, 1>  two waves per SIMD, 32 rows each;   <4, 2>  one wave per SIMD, 64 rows each (every weight fragment read from LDS feeds two MFMAs:
+//   at 32 rows per wave the fragment reads alone need the whole LDS port, 1 KiB per 32-cycle MFMA per SIMD);   <4, 1>  128-row blocks for
+//   shapes the other two do not divide.
+// One iteration of the slab loop = the 40 * RF MFMAs of slab j in 10 fenced steps of 2 k-steps, with the PREVIOUS slab's output path slotted
+// between them: its tile was rounded to bf16 (bias added) into 16 * RF registers at the top of the iteration, ahead of the barrier; steps 0-4
+// carry the LDS-DMA pieces of slab j + 2 and the staging writes, steps 5-7 the staging reads and the 16-byte-per-lane global stores.  (The
+// first version ran "multiply, then stage, then store" per slab with all waves in the same phase: 5900 cycles per slab for 2560 of MFMA.)
+template <int C, int NW, int RF, bool DBG = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
-    constexpr int NK = C / 16;                  // k16 steps = resident row fragments
+    constexpr int NK = C / 16;                  // k16 steps = resident row fragments per 32 rows
     constexpr int NT = C / 32;                  // 32-k LDS stages of a slab
     constexpr int SLAB = 64 * C * 2;            // 64 weight rows
     constexpr int PPW = NT * 4 / NW;            // 1-KiB pieces per wave per slab
-    constexpr int BR = 32 * NW;                 // rows per block
-    static_assert(PPW * NW == NT * 4, "pieces per wave");
+    constexpr int RW = 32 * RF;                 // rows per wave
+    constexpr int BR = RW * NW;                 // rows per block
+    constexpr int NSTEP = NK / 4 * 2;           // fenced steps of 2 k-steps
+    constexpr int NST = RW / 8;                 // 1-KiB store instructions per wave per slab
+    constexpr int NP = RF * 8;                  // (row fragment, channel half, g) register pairs of a tile
+    static_assert(PPW * NW == NT * 4 && PPW % 5 == 0 && NK % 4 == 0 && NSTEP == 10, "schedule below is written for C = 320");
     constexpr int NSLOT = 3;
-    constexpr int GB_OFF = NSLOT * SLAB;        // output bias (W beta) copy
-    constexpr int ST_OFF = GB_OFF + 960 * 4;    // (output bias copy: N <= 960 floats)  // per-wave output staging: 32 rows x (128 + 16) B, or 64 rows x (64 + 16) B for the transposed slabs
-    constexpr int ST_BYTES = 32 * 144;          // 4608 >= 64 * 64 (the transposed tile is stored unpadded: LDS is full at 8 waves)
+    constexpr int ST_BYTES = RW * 144;          // per-wave output staging: RW rows x (128 + 16) B row-major; 64 channel rows x RW tokens (swizzled) transposed
+    constexpr int RB = RW * 2, NCH = RB / 16;   // transposed staging tile: bytes and 16-byte chunks per channel row
+    // ONE LDS object, and the staging writes as inline asm: with LDS-DMA in flight the compiler's wait-count pass puts s_waitcnt vmcnt(0) in
+    // front of every ds_write it can see (the first version's 1200-cycle "staging" phase was that wait); with several LDS objects it has alias
+    // scopes and spares the staging writes, but then makes every ring READ wait for the DMA piece issued just before it.  A single object
+    // gets no such waits on loads, and it cannot see these stores.
+    constexpr int GB_OFF = NSLOT * SLAB;        // output bias (W beta) copy: N <= 960 floats
+    constexpr int ST_OFF = GB_OFF + 960 * 4;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[ST_OFF + NW * ST_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,6 +85,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
     const int nrm_slabs = p.n_rm / 64;
     float* gsm = reinterpret_cast<float*>(lds + GB_OFF);
     unsigned char* stg = lds + ST_OFF + wave * ST_BYTES;
+    const unsigned stg_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)stg;      // LDS byte address
 
     for (int c = tid; c < p.N; c += 64 * NW) gsm[c] = p.bias ? p.bias[c] : 0.f;
 
@@ -81,12 +95,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
     const long long my_blocks = (nblocks - (long long)blockIdx.x + gridDim.x - 1) / gridDim.x;
     const long long total = my_blocks * nslab;
     int ld_slab = 0, ld_slot = 0;
-    auto issue_slab = [&]() __attribute__((always_inline)) {
-        unsigned char* dst = lds + ld_slot * SLAB;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + (wave + NW * i) * 1024), 16, (int)voff,
-                                                     ld_slab * SLAB + i * NW * 1024, 0, 0);
+    bool ld_live = true;
+    auto issue_piece = [&](int i) __attribute__((always_inline)) {      // piece i of this wave's PPW pieces of the slab being loaded
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + ld_slot * SLAB + (wave + NW * i) * 1024), 16,
+                                                 (int)(ld_live ? voff : kInvalid), ld_live ? ld_slab * SLAB + i * NW * 1024 : 0, 0, 0);
+    };
+    auto advance_load = [&]() __attribute__((always_inline)) {
         ld_slab = (ld_slab + 1 == nslab) ? 0 : ld_slab + 1;
         ld_slot = (ld_slot + 1 == NSLOT) ? 0 : ld_slot + 1;
     };
@@ -95,173 +109,253 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
     const int foff0 = l31 * 64 + (((0 + hi) ^ pj_swz(l31)) * 16);
     const int foff1 = l31 * 64 + (((2 + hi) ^ pj_swz(l31)) * 16);
 
-    bf16x8 xr[NK];
+    bf16x8 xr[RF][NK];
     auto load_rows = [&](long long blk) __attribute__((always_inline)) {
-        const bf16_t* xz = p.x + (blk * BR + wave * 32 + l31) * p.ldx + hi * 8;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) xr[k] = *reinterpret_cast<const bf16x8*>(xz + k * 16);
+        for (int r = 0; r < RF; ++r) {
+            const bf16_t* xz = p.x + (blk * BR + wave * RW + r * 32 + l31) * p.ldx + hi * 8;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) xr[r][k] = *reinterpret_cast<const bf16x8*>(xz + k * 16);
+        }
     };
-    // LayerNorm of the wave's 32 rows in place: lane (l31, hi) holds channels 16 k + 8 hi .. + 7 of row l31, its partner lane the rest.
+    // LayerNorm of the wave's rows in place: lane (l31, hi) holds channels 16 k + 8 hi .. + 7 of row r * 32 + l31, its partner lane the rest.
     // gamma and beta are folded into the weights / the output bias at pack time (W diag(gamma), W beta), so this is (x - mean) * rstd only.
-    // A wave alone on its SIMD issues one VALU instruction per ~4-5 cycles, so the instruction count is what matters here: sums and sums of
-    // squares by v_dot2_f32_bf16 on the packed pairs (1 instruction per 2 elements, exact bf16 products, fp32 accumulation) instead of unpack +
-    // add / fma; variance as E[x^2] - mean^2 in fp32 (the first version: 3 unpacking passes + gamma / beta from LDS = 37k cycles per block).
+    // Sums and sums of squares by v_dot2_f32_bf16 on the packed pairs (1 instruction per 2 elements, exact bf16 products, fp32 accumulation)
+    // instead of unpack + add / fma; variance as E[x^2] - mean^2 in fp32 (the first version: 3 unpacking passes + gamma / beta from LDS =
+    // 37k cycles per block).
     typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
     auto normalise = [&]() __attribute__((always_inline)) {
         const bf16x2v ones = __builtin_bit_cast(bf16x2v, 0x3f803f80u);
-        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            // (element pairs picked with shufflevector: the u32x4 bit_cast + runtime-indexed subscript form of this loop was miscompiled by
-            //  ROCm 7.2's clang - every dot2 read dword 0 of the fragment)
-            const bf16x2v a = __builtin_shufflevector(xr[k], xr[k], 0, 1), b = __builtin_shufflevector(xr[k], xr[k], 2, 3);
-            const bf16x2v c = __builtin_shufflevector(xr[k], xr[k], 4, 5), d = __builtin_shufflevector(xr[k], xr[k], 6, 7);
-            s0 = __builtin_amdgcn_fdot2_f32_bf16(a, ones, s0, false);
-            s1 = __builtin_amdgcn_fdot2_f32_bf16(b, ones, s1, false);
-            q0 = __builtin_amdgcn_fdot2_f32_bf16(a, a, q0, false);
-            q1 = __builtin_amdgcn_fdot2_f32_bf16(b, b, q1, false);
-            s0 = __builtin_amdgcn_fdot2_f32_bf16(c, ones, s0, false);
-            s1 = __builtin_amdgcn_fdot2_f32_bf16(d, ones, s1, false);
-            q0 = __builtin_amdgcn_fdot2_f32_bf16(c, c, q0, false);
-            q1 = __builtin_amdgcn_fdot2_f32_bf16(d, d, q1, false);
-        }
-        float s = s0 + s1, q = q0 + q1;
-        s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 32, 64);
-        const float mean = s * (1.0f / C);
-        const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + p.eps);
-        const float sh = -mean * rstd;
+        for (int r = 0; r < RF; ++r) {
+            float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const u32x4 u = __builtin_bit_cast(u32x4, xr[k]);
-            u32x4 o;
+            for (int k = 0; k < NK; ++k) {
+                // (element pairs picked with shufflevector: the u32x4 bit_cast + subscript form of this loop was miscompiled by ROCm 7.2's
+                //  clang - every dot2 read dword 0 of the fragment)
+                const bf16x2v a = __builtin_shufflevector(xr[r][k], xr[r][k], 0, 1), b = __builtin_shufflevector(xr[r][k], xr[r][k], 2, 3);
+                const bf16x2v c = __builtin_shufflevector(xr[r][k], xr[r][k], 4, 5), d = __builtin_shufflevector(xr[r][k], xr[r][k], 6, 7);
+                s0 = __builtin_amdgcn_fdot2_f32_bf16(a, ones, s0, false);
+                s1 = __builtin_amdgcn_fdot2_f32_bf16(b, ones, s1, false);
+                q0 = __builtin_amdgcn_fdot2_f32_bf16(a, a, q0, false);
+                q1 = __builtin_amdgcn_fdot2_f32_bf16(b, b, q1, false);
+                s0 = __builtin_amdgcn_fdot2_f32_bf16(c, ones, s0, false);
+                s1 = __builtin_amdgcn_fdot2_f32_bf16(d, ones, s1, false);
+                q0 = __builtin_amdgcn_fdot2_f32_bf16(c, c, q0, false);
+                q1 = __builtin_amdgcn_fdot2_f32_bf16(d, d, q1, false);
+            }
+            float s = s0 + s1, q = q0 + q1;
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            const float mean = s * (1.0f / C);
+            const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + p.eps);
+            const float sh = -mean * rstd;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack2bf(__builtin_fmaf(bflo(u[e]), rstd, sh), __builtin_fmaf(bfhi(u[e]), rstd, sh));
-            xr[k] = __builtin_bit_cast(bf16x8, o);
+            for (int k = 0; k < NK; ++k) {
+                const u32x4 u = __builtin_bit_cast(u32x4, xr[r][k]);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2bf(__builtin_fmaf(bflo(u[e]), rstd, sh), __builtin_fmaf(bfhi(u[e]), rstd, sh));
+                xr[r][k] = __builtin_bit_cast(bf16x8, o);
+            }
         }
     };
 
-    issue_slab();
-    issue_slab();
-    load_rows(blockIdx.x);
-    __syncthreads();                       // the output bias copy is visible (drains the two slabs in flight once, at kernel start)
+    // ---- output path of one slab tile, cut into the pieces the slab loop slots between its MFMAs
+    //   row-major (TRE = 0): acc[r][t][4 g + c] = out[token row0 + 32 r + l31][channel 64 sl + 32 t + 8 g + 4 hi + c]
+    //   transposed (TRE = 1): acc[r][t][4 g + c] = outT[image][channel 64 (sl - nrm_slabs) + 32 t + l31][token pix0 + 32 r + 8 g + 4 hi + c]
+    f32x16 acc[RF][2];
+    u32x2 pk[RF][2][4];
+    u32x4 sr[NST];
+    long long p_row0 = 0, p_img = 0, p_pix0 = 0;    // the tile in pk / staging: its rows and slab
+    int p_sl = 0;
+    auto tswz = [&](int row) __attribute__((always_inline)) { return (NCH == 4 ? (row >> 1) : row) & (NCH - 1); };
+    auto pack_tile = [&](auto tre_) __attribute__((always_inline)) {
+        constexpr bool TRE = decltype(tre_)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if constexpr (!TRE) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(gsm + p_sl * 64 + t * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int r = 0; r < RF; ++r)
+                        pk[r][t][g] = u32x2{pack2bf(acc[r][t][4 * g + 0] + bb[0], acc[r][t][4 * g + 1] + bb[1]),
+                                            pack2bf(acc[r][t][4 * g + 2] + bb[2], acc[r][t][4 * g + 3] + bb[3])};
+                }
+            } else {
+                const float bb = gsm[p_sl * 64 + t * 32 + l31];
+#pragma unroll
+                for (int r = 0; r < RF; ++r)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        pk[r][t][g] = u32x2{pack2bf(acc[r][t][4 * g + 0] + bb, acc[r][t][4 * g + 1] + bb),
+                                            pack2bf(acc[r][t][4 * g + 2] + bb, acc[r][t][4 * g + 3] + bb)};
+            }
+        }
+    };
+    auto stage_write = [&](auto tre_, auto i_) __attribute__((always_inline)) {       // pair i = (r, t, g)
+        constexpr bool TRE = decltype(tre_)::value;
+        constexpr int i = decltype(i_)::value, r = i / 8, t = (i / 4) & 1, g = i & 3;
+        if constexpr (!TRE) {
+            const unsigned a = stg_a + l31 * 144 + hi * 8;
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(pk[r][t][g]), "n"(r * 32 * 144 + (t * 32 + 8 * g) * 2) : "memory");
+        } else {
+            const int row = t * 32 + l31;
+            const unsigned a = stg_a + row * RB + (((r * 4 + g) ^ tswz(row)) * 16) + hi * 8;
+            asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(pk[r][t][g]) : "memory");
+        }
+    };
+    auto stage_read = [&](auto tre_, auto i_) __attribute__((always_inline)) {
+        constexpr bool TRE = decltype(tre_)::value;
+        constexpr int it = decltype(i_)::value;
+        if constexpr (!TRE) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            sr[it] = *reinterpret_cast<const u32x4*>(stg + row * 144 + ch * 16);
+        } else {
+            const int row = it * (64 / NCH) + lane / NCH, ch = lane % NCH;      // channel row of the slab, 16-byte piece of its RW tokens
+            sr[it] = *reinterpret_cast<const u32x4*>(stg + row * RB + ((ch ^ tswz(row)) * 16));
+        }
+    };
+    auto store_out = [&](auto tre_, auto i_) __attribute__((always_inline)) {
+        constexpr bool TRE = decltype(tre_)::value;
+        constexpr int it = decltype(i_)::value;
+        if constexpr (!TRE) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            *reinterpret_cast<u32x4*>(p.out + (p_row0 + row) * p.ldo + p_sl * 64 + ch * 8) = sr[it];
+        } else {
+            const int row = it * (64 / NCH) + lane / NCH, ch = lane % NCH;
+            *reinterpret_cast<u32x4*>(p.outT + (p_img * p.Ct + (p_sl - nrm_slabs) * 64 + row) * p.S + p_pix0 + ch * 8) = sr[it];
+        }
+    };
+
+    auto issue_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) issue_piece(i);
+        advance_load();
+    };
+    issue_all();
+    issue_all();
+#pragma unroll
+    for (int r = 0; r < RF; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.f;
 
     long long j = 0;                       // weight-stream index of the slab about to be consumed
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (DBG && blockIdx.x == 0 && j >= 16 && j < 48 && lane == 0) g_pj_dbg[(wave * 32 + (int)(j - 16)) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
-    int rd_slot = 0;
-    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        normalise();
-        const long long row0 = blk * BR + wave * 32;
-        const long long img = row0 / p.S, pix0 = row0 - img * p.S;
-        for (int sl = 0; sl < nslab; ++sl, ++j) {
-            // this wave's pieces of slab j have landed when only the ops issued after them are outstanding: the next slab's PPW pieces,
-            // the stores of the last two slabs (4 each) and - on the first two slabs of a block - the 20 row loads of the next block
-            stamp(0);
-            if (j < 2 || sl < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (after a block boundary the row loads sit in the queue: drain once)
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 8) : "memory");
-            stamp(1);
-            __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone finished reading the slot refilled below
-            asm volatile("" ::: "memory");
-            stamp(2);
-            if (j + 2 < total) issue_slab();
-            else {                                   // stream tail: keep the per-slab op count constant for the counted waits
+    int rd_slot = 0, sl = 0;
+    long long blk = blockIdx.x, row0 = 0, img = 0, pix0 = 0;
+
+    // one slab: multiply slab `sl` of the current block (TRM: transposed output, MFMA operands swapped), push the previous tile (TRE) out
+    auto iter = [&](auto trm_, auto tre_) __attribute__((always_inline)) {
+        constexpr bool TRM = decltype(trm_)::value;
+        pack_tile(tre_);
 #pragma unroll
-                for (int i = 0; i < PPW; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + ld_slot * SLAB + (wave + NW * i) * 1024), 16,
-                                                             (int)kInvalid, 0, 0, 0);
-                ld_slot = (ld_slot + 1 == NSLOT) ? 0 : ld_slot + 1;
-            }
-            stamp(3);
-            const unsigned char* sb = lds + rd_slot * SLAB;
-            rd_slot = (rd_slot + 1 == NSLOT) ? 0 : rd_slot + 1;
-            f32x16 acc[2];
+        for (int r = 0; r < RF; ++r)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            const bool transposed = sl >= nrm_slabs;   // wave-uniform
-            if (!transposed) {
-                // (groups of 4 k-steps fenced off from each other: left alone the scheduler hoists all 40 fragment reads of a slab to the top,
-                //  spills, and the scratch reloads' vmcnt(0) waits drain the LDS-DMA stream)
-                pj_static_for<0, NK / 4>([&](auto g_) {
-                    constexpr int g4 = decltype(g_)::value;
-                    bf16x8 wf[4][2];
+                for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.f;
+        // this wave's pieces of slab j have landed when only the ops issued after them are outstanding: the stores of tile j - 3 (issued
+        // after the pieces in iteration j - 2), and iteration j - 1's pieces and stores.  Around a block boundary (row loads in the queue,
+        // no stores in the very first iteration) drain instead.
+        stamp(0);
+        if (j < 3 || sl < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * NST) : "memory");
+        stamp(1);
+        __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone finished reading the slot refilled below
+        asm volatile("" ::: "memory");
+        stamp(2);
+        ld_live = j + 2 < total;               // stream tail: dummy pieces keep the per-iteration op count constant for the counted waits
+        const unsigned char* sb = lds + rd_slot * SLAB;
+        rd_slot = (rd_slot + 1 == NSLOT) ? 0 : rd_slot + 1;
+        const bool have_prev = j > 0;
+        bf16x8 wf[2][2][2];                    // [buffer][k-step of the pair][channel half]
+        auto load_frags = [&](auto s_) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_)::value;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            wf[q][t] = *reinterpret_cast<const bf16x8*>(sb + ((g4 * 4 + q) >> 1) * 4096 + t * 2048 + (((g4 * 4 + q) & 1) ? foff1 : foff0));
-                    pj_static_for<0, 4>([&](auto q_) {
-                        constexpr int q = decltype(q_)::value;
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q][0], xr[g4 * 4 + q], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q][1], xr[g4 * 4 + q], acc[1], 0, 0, 0);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                // acc[t][4 g + c] = out[token row0 + l31][channel 64 sl + 32 t + 8 g + 4 hi + c]
-                stamp(4);
-                // through the wave's LDS staging tile, then whole 128-byte row segments as 16-byte-per-lane stores: 8-byte stores at a row
-                // stride (32 rows per instruction) are store-ISSUE bound - the first version of this kernel spent 2/3 of its time in them
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                    {
-                        const float4 bb = *reinterpret_cast<const float4*>(gsm + sl * 64 + t * 32 + 8 * g + 4 * hi);
-                        *reinterpret_cast<uint2*>(stg + l31 * 144 + (t * 32 + 8 * g + 4 * hi) * 2) =
-                            make_uint2(pack2bf(acc[t][4 * g + 0] + bb.x, acc[t][4 * g + 1] + bb.y), pack2bf(acc[t][4 * g + 2] + bb.z, acc[t][4 * g + 3] + bb.w));
+                    wf[s & 1][q][t] = *reinterpret_cast<const bf16x8*>(sb + s * 4096 + t * 2048 + (q ? foff1 : foff0));
+        };
+        load_frags(std::integral_constant<int, 0>{});
+        pj_static_for<0, NSTEP>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            if constexpr (s + 1 < NSTEP) load_frags(std::integral_constant<int, s + 1>{});
+            pj_static_for<0, 2>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                pj_static_for<0, RF>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    if constexpr (!TRM) {
+                        acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][q][0], xr[r][2 * s + q], acc[r][0], 0, 0, 0);
+                        acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][q][1], xr[r][2 * s + q], acc[r][1], 0, 0, 0);
+                    } else {
+                        acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[r][2 * s + q], wf[s & 1][q][0], acc[r][0], 0, 0, 0);
+                        acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[r][2 * s + q], wf[s & 1][q][1], acc[r][1], 0, 0, 0);
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                bf16_t* op = p.out + row0 * p.ldo + sl * 64;
-                stamp(5);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = it * 8 + (lane >> 3), ch = lane & 7;
-                    *reinterpret_cast<u32x4*>(op + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const u32x4*>(stg + row * 144 + ch * 16);
-                }
-                stamp(6);
-            } else {
-                pj_static_for<0, NK / 4>([&](auto g_) {
-                    constexpr int g4 = decltype(g_)::value;
-                    bf16x8 wf[4][2];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            wf[q][t] = *reinterpret_cast<const bf16x8*>(sb + ((g4 * 4 + q) >> 1) * 4096 + t * 2048 + (((g4 * 4 + q) & 1) ? foff1 : foff0));
-                    pj_static_for<0, 4>([&](auto q_) {
-                        constexpr int q = decltype(q_)::value;
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[g4 * 4 + q], wf[q][0], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[g4 * 4 + q], wf[q][1], acc[1], 0, 0, 0);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
                 });
-                // acc[t][4 g + c] = outT[image][channel 64 (sl - nrm_slabs) + 32 t + l31][token pix0 + 8 g + 4 hi + c]
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                    {
-                        const float bb = gsm[sl * 64 + t * 32 + l31];
-                        *reinterpret_cast<uint2*>(stg + (t * 32 + l31) * 64 + (8 * g + 4 * hi) * 2) =
-                            make_uint2(pack2bf(acc[t][4 * g + 0] + bb, acc[t][4 * g + 1] + bb), pack2bf(acc[t][4 * g + 2] + bb, acc[t][4 * g + 3] + bb));
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                bf16_t* op = p.outT + (img * p.Ct + (sl - nrm_slabs) * 64) * p.S + pix0;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = it * 16 + (lane >> 2), ch = lane & 3;      // channel row of the slab, 16-byte piece of its 32 tokens
-                    *reinterpret_cast<u32x4*>(op + (long long)row * p.S + ch * 8) = *reinterpret_cast<const u32x4*>(stg + row * 64 + ch * 16);
-                }
+            });
+            if constexpr (s < 5) {
+                pj_static_for<s * (PPW / 5), (s + 1) * (PPW / 5)>([&](auto i_) { issue_piece(decltype(i_)::value); });
+                pj_static_for<s * NP / 5, (s + 1) * NP / 5>([&](auto i_) { stage_write(tre_, i_); });
+            } else if constexpr (s == 5) {
+                pj_static_for<0, NST / 2>([&](auto i_) { stage_read(tre_, i_); });
+            } else if constexpr (s == 6) {
+                if (have_prev) pj_static_for<0, NST / 2>([&](auto i_) { store_out(tre_, i_); });
+                pj_static_for<NST / 2, NST>([&](auto i_) { stage_read(tre_, i_); });
+            } else if constexpr (s == 7) {
+                if (have_prev) pj_static_for<NST / 2, NST>([&](auto i_) { store_out(tre_, i_); });
             }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        advance_load();
+        stamp(3);
+    };
+
+    // (rows are loaded AND normalised in one place, so that no row load is pending on the loop back edge: with the normalisation at the top
+    //  of the next iteration the compiler kept vmcnt(10..20) waits in front of the MFMAs of every step, which drain the weight stream)
+    auto begin_block = [&]() __attribute__((always_inline)) {
+        load_rows(blk);
+        normalise();
+        row0 = blk * BR + wave * RW;
+        img = row0 / p.S;
+        pix0 = row0 - img * p.S;
+    };
+    if (total > 0) begin_block();
+    __syncthreads();                       // the output bias copy is visible
+    for (; j < total; ++j) {
+        const bool trm = sl >= nrm_slabs, tre = p_sl >= nrm_slabs;      // wave-uniform
+        if (!trm) {
+            if (!tre) iter(std::false_type{}, std::false_type{});
+            else iter(std::false_type{}, std::true_type{});
+        } else {
+            if (!tre) iter(std::true_type{}, std::false_type{});
+            else iter(std::true_type{}, std::true_type{});
         }
-        // the next block's rows come straight into the (now dead) fragment registers: the load latency is exposed once per block, but a
-        // second register set held across the block spilled, and the scratch reloads' vmcnt(0) waits drained the LDS-DMA stream
-        const long long nxt = blk + gridDim.x;
-        if (nxt < nblocks) load_rows(nxt);
+        p_row0 = row0; p_img = img; p_pix0 = pix0; p_sl = sl;
+        if (++sl == nslab) {
+            // the next block's rows come straight into the (now dead) fragment registers: the load latency is exposed once per block
+            sl = 0;
+            blk += gridDim.x;
+            if (blk < nblocks) begin_block();
+        }
+    }
+    // the last tile
+    auto drain = [&](auto tre_) __attribute__((always_inline)) {
+        pack_tile(tre_);
+        pj_static_for<0, NP>([&](auto i_) { stage_write(tre_, i_); });
+        pj_static_for<0, NST>([&](auto i_) { stage_read(tre_, i_); });
+        pj_static_for<0, NST>([&](auto i_) { store_out(tre_, i_); });
+    };
+    if (total > 0) {
+        if (p_sl >= nrm_slabs) drain(std::true_type{});
+        else drain(std::false_type{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -290,19 +384,21 @@ extern "C" int v3d_ln_proj(const void* x, int64_t ldx, float eps, const void* Wp
     p.N = N; p.n_rm = n_rm; p.Ct = N - n_rm;
     p.w_bytes = (unsigned)((size_t)N * C * 2);
     p.eps = eps;
-    static int tl = -1, w4 = -1;
+    static int tl = -1, cfg = -1;
     if (tl < 0) { const char* e = getenv("V3D_LNPROJ_TIMELINE"); tl = e ? atoi(e) : 0; }
-    if (w4 < 0) { const char* e = getenv("V3D_LNPROJ_WAVES"); w4 = e ? atoi(e) : 8; }     // A/B knob: 4 = one wave per SIMD, 128-row blocks
-    const bool eight = w4 != 4 && M % 256 == 0 && (n_rm == N || S % 256 == 0);
-    const long long nblocks = M / (eight ? 256 : 128);
+    if (cfg < 0) { const char* e = getenv("V3D_LNPROJ_CFG"); cfg = e ? atoi(e) : 1; }     // A/B knob: 0 = <4 waves, 64 rows> (161 us at level 0), 1 = <8, 32> (148 us, default), 2 = <4, 32> (164 us)
+    const bool big = cfg != 2 && M % 256 == 0 && (n_rm == N || S % 256 == 0);
+    const long long nblocks = M / (big ? 256 : 128);
     const int cus = v3d_num_cus();
     const int grid = nblocks < cus ? (int)nblocks : cus;
-    if (eight) {
-        if (tl) hipLaunchKernelGGL((ln_proj_kernel<320, 8, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((ln_proj_kernel<320, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    if (big && cfg == 0) {
+        if (tl) hipLaunchKernelGGL((ln_proj_kernel<320, 4, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((ln_proj_kernel<320, 4, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (big) {
+        if (tl) hipLaunchKernelGGL((ln_proj_kernel<320, 8, 1, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((ln_proj_kernel<320, 8, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
     } else {
-        if (tl) hipLaunchKernelGGL((ln_proj_kernel<320, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((ln_proj_kernel<320, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((ln_proj_kernel<320, 4, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     }
     return v3d_check_launch("v3d_ln_proj");
 }
