@@ -96,7 +96,9 @@ typedef struct v3d_gemm_args {
     int64_t halo_rows;                        /* CONVT3 (ABI 3): 0 = dense frames; B*S = split-halo layout, see above */
     /* (ABI 3) GroupNorm statistics of the OUTPUT, accumulated by the epilogue so that the next GroupNorm needs no statistics pass:
      * gn_stats[(m / gn_rps)][slot][n / gn_cpg][2] += (sum, sumsq) of the bf16-rounded out[m][n]  (layout of v3d_groupnorm_stats,
-     * V3D_GN_SLOTS slots, caller zeroes).  NULL = off.  Needs bf16 out, !geglu, N % gn_cpg == 0, 32 groups (N / gn_cpg == 32). */
+     * V3D_GN_SLOTS slots, caller zeroes).  NULL = off.  Needs a dense bf16 out (ldo == N), !geglu, batch 1, 32 groups of an even number of channels (N == 32 * gn_cpg), gn_rps % 16 == 0,
+     * M % gn_rps == 0.  The persistent big-tile kernels gather the sums in their epilogue; every other launch runs v3d_groupnorm_stats on the
+     * output before returning (same result). */
     float* gn_stats;
     int64_t gn_rps;                           /* rows per statistics group (imgs_per_stat * S) */
     int32_t gn_cpg;                           /* channels per group */

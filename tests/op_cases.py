@@ -34,7 +34,9 @@ def compare(a: torch.Tensor, b: torch.Tensor):
 
 # ------------------------------------------------------------------------------------------------
 def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=True, add=False, res=0, coef=False,
-              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0):
+              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0, gn_rps=0):
+    """gn_rps > 0: the launch also gathers the GroupNorm partial sums of its output (GemmCall.gn_stats, 32 groups, gn_rps rows per statistics
+    group); they are checked against sums over the rows the kernel itself stored (fp32 atomics: order-dependent, 2e-4 of the largest sum)."""
     g = torch.Generator().manual_seed(seed)
     kw = {}
     n_out = N // 2 if geglu else N
@@ -79,6 +81,20 @@ def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=Tru
         rpg = max(1, M // 5)
         kw.update(coef=_rand(g, ((M + rpg - 1) // rpg, 3), F32, 1.0, dev), coef_rpg=rpg)
     base = dict(A=A, W=W, M=M, N=N, K=K, mode=mode, geglu=geglu, batch=batch, **kw)
+    if gn_rps:
+        from v3d_amd.ops import GN_SLOTS
+        st_h = torch.zeros((M // gn_rps, GN_SLOTS, 32, 2), dtype=F32, device=dev)
+        st_e = torch.zeros_like(st_h)
+        hip.gemm(GemmCall(out=out_h, gn_stats=st_h, gn_rps=gn_rps, gn_cpg=N // 32, **base))
+        emu.gemm(GemmCall(out=out_e, gn_stats=st_e, gn_rps=gn_rps, gn_cpg=N // 32, **base))
+        v = out_h.float().reshape(M // gn_rps, gn_rps, 32, N // 32)
+        want = torch.stack([v.sum(dim=(1, 3)), (v * v).sum(dim=(1, 3))], dim=-1)
+        got = st_h.sum(dim=1)
+        err = ((got - want).abs().max() / want.abs().max()).item()
+        assert err <= 2e-4, f"gn_stats epilogue: partial sums off by {err:.3e} of the largest sum"
+        r_e, _ = compare(st_e.sum(dim=1), want)
+        assert r_e <= 2e-2, f"emulated gn_stats far from the kernel's ({r_e:.3e})"
+        return compare(out_h, out_e)
     hip.gemm(GemmCall(out=out_h, **base))
     emu.gemm(GemmCall(out=out_e, **base))
     return compare(out_h, out_e)
@@ -380,6 +396,15 @@ def all_cases(full: bool = True):
         ("convt3_split_halo_mid", case_convt3_split_halo, dict(B=2, T=3, S=16, N=64, K=64), TOL_BF16),
         ("convt3_split_halo_first", case_convt3_split_halo, dict(B=2, T=2, S=40, N=72, K=64, first=True), TOL_BF16),
         ("convt3_split_halo_last_v3", case_convt3_split_halo, dict(B=2, T=9, S=256, N=320, K=320, last=True), TOL_BF16),
+        # GroupNorm partial sums gathered by the producing GEMM (v3 <GN> epilogue; other kernels fall back to the stand-alone pass inside v3d_gemm)
+        ("gn_epi_conv_L0_straddle", case_gemm, dict(M=0, N=320, K=320, mode=GEMM_CONV3X3, conv=(3, 64, 64, 1, 1), gn_rps=4096, res=1), TOL_BF16),
+        ("gn_epi_conv_3d", case_gemm, dict(M=0, N=320, K=64, mode=GEMM_CONV3X3, conv=(6, 32, 32, 1, 1), gn_rps=3 * 1024, add=True, seed=1), TOL_BF16),
+        ("gn_epi_conv_8x8", case_gemm, dict(M=0, N=1280, K=128, mode=GEMM_CONV3X3, conv=(36, 8, 8, 1, 1), gn_rps=64, seed=2), TOL_BF16),
+        ("gn_epi_conv_256tile", case_gemm, dict(M=0, N=512, K=96, mode=GEMM_CONV3X3, conv=(8, 32, 32, 1, 1), gn_rps=1024, seed=3), TOL_BF16),
+        ("gn_epi_convt3", case_gemm, dict(M=0, N=320, K=320, mode=GEMM_CONVT3, convt=(2, 3, 1024, 1, 0, 2), gn_rps=3 * 1024, res=1, coef=True, seed=4), TOL_BF16),
+        ("gn_epi_linear", case_gemm, dict(M=192 * 9, N=320, K=320, gn_rps=192 * 3, res=1, seed=5), TOL_BF16),
+        ("gn_epi_fallback_v2", case_gemm, dict(M=0, N=128, K=64, mode=GEMM_CONV3X3, conv=(2, 16, 16, 1, 1), gn_rps=256, seed=6), TOL_BF16),
+        ("gn_epi_fallback_ragged", case_gemm, dict(M=0, N=320, K=64, mode=GEMM_CONV3X3, conv=(3, 20, 20, 1, 1), gn_rps=400, seed=7), TOL_BF16),
         ("ln_proj_qkv_spatial", case_ln_proj, dict(M=3 * 256, N=960, n_rm=640, S=256), TOL_BF16),
         ("ln_proj_qkv_temporal", case_ln_proj, dict(M=128 * 5, N=960, n_rm=960, S=128, seed=1), TOL_BF16),
         ("ln_proj_all_transposed", case_ln_proj, dict(M=2 * 128, N=128, n_rm=0, S=128, seed=2), TOL_BF16),

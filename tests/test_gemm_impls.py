@@ -18,3 +18,7 @@ def test_gemm_parity_with_forced_impl(impl, extra):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gemm parity failures: 0" in r.stdout, r.stdout + r.stderr
+    if impl == "3":      # the gn_epi_* cases must have gone through the v3 <GN> epilogue (not the stand-alone fallback inside v3d_gemm)
+        import re
+        m = re.search(r"gn epilogue launches: (\d+)", r.stdout)
+        assert m and int(m.group(1)) >= 5, r.stdout

@@ -28,6 +28,9 @@ if "--check" in sys.argv:
         if not ok:
             print(f"[{tag}] FAIL {name} rel={rel:.3e} cos={cos:.6f}")
     print(f"[{tag}] gemm parity failures: {bad}")
+    import ctypes
+    hip.lib.v3d_debug_gn_epilogue_launches.restype = ctypes.c_longlong
+    print(f"[{tag}] gn epilogue launches: {hip.lib.v3d_debug_gn_epilogue_launches()}")
 shapes = [
     ("lin_L0_320x320", dict(M=36 * 4096, N=320, K=320)),
     ("lin_L0_ff1_geglu", dict(M=36 * 4096, N=2560, K=320, geglu=True)),

@@ -25,6 +25,14 @@ __device__ __forceinline__ u32x4 buf_load16(bufrsrc_t r, unsigned byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
 }
 
+
+
+// LDS stores the compiler's wait-count pass cannot see.  With LDS-DMA (buffer_load ... lds) in flight it puts s_waitcnt vmcnt(0) in front of
+// every ds_write to the same LDS object (a DMA piece might still be landing there).  The callers write wave-private regions that no DMA ever
+// targets.  LDS executes a wave's operations in order, so later ds_reads of the same addresses need no extra wait.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void lds_store16_nowait(void* p, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory"); }
+
 #define V3D_WAVE 64
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }

@@ -74,6 +74,9 @@ struct GP {
     int split_n;         // > 1: split-K launch: blockIdx.y = split index = output slab (out = fp32 workspace [split][M][N], plain stores)
     const float* ws;     // finalize kernel only: the workspace to reduce
     int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads
+    float* gn_stats;     // GroupNorm partial sums of the output [M / gn_rps][V3D_GN_SLOTS][32][2], accumulated by the v3 <GN> epilogue (else NULL)
+    long long gn_rps;    // rows per statistics group
+    int gn_cpg;          // channels per group (N / 32)
 };
 
 // 64 KiB of zeros: an invalid (padding / tail) lane of the LDS-DMA points here and can still be advanced by k0 like a
@@ -218,10 +221,77 @@ __device__ __forceinline__ void res_piece_to_stage(u32x4 r, unsigned char* stage
     }
 }
 
-template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false, int SPAD = 16>
+// ---- GroupNorm statistics of the output, gathered where it is produced (v3 <GN> kernels) ----------------------------------------
+// Every ResBlock convolution is followed by a GroupNorm of its output (openaimodel.py:267-271,302-305 / video_model.py:42-55); the
+// stand-alone statistics kernel re-reads that tensor from HBM.  Here a wave adds up (sum, sum of squares) of the bf16-ROUNDED values it
+// stores - the numbers v3d_groupnorm_stats would read back - per channel over the rows of its tile that belong to one statistics group
+// (rows / gn_rps: an image, or the T images of a sample for the 3-D norm): in registers over the row fragments, across the 16 pixel lanes
+// with DPP row shifts, through the wave's staging region to one lane per GroupNorm group, then 2 fp32 atomics per group into the same
+// [stat][slot][32][2] buffer the stand-alone kernel fills.
+template <int NF>
+struct GnAcc {
+    float s[NF][2], q[NF][2];     // per fragment column j: channel pairs (4 q + 0, 1) and (4 q + 2, 3) of the lane's 4 channels - groups hold an even
+};                                // number of channels, so a pair never straddles two of them
+template <int NF>
+__device__ __forceinline__ void gn_zero(GnAcc<NF>& a) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j) a.s[j][0] = a.s[j][1] = a.q[j][0] = a.q[j][1] = 0.f;
+}
+// one packed bf16 pair of the stored tile: sum and sum of squares by v_dot2_f32_bf16 (exact products, fp32 accumulation, no unpacking)
+typedef __bf16 gn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gn_add_pair(float& s, float& q, uint32_t w) {
+    const gn_bf16x2 v = __builtin_bit_cast(gn_bf16x2, w), ones = __builtin_bit_cast(gn_bf16x2, 0x3f803f80u);
+    s = __builtin_amdgcn_fdot2_f32_bf16(v, ones, s, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(v, v, q, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr(float v) {    // value of the lane CTRL positions below in the 16-lane row, 0 past the row start
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 | CTRL, 0xf, 0xf, true));
+}
+template <int NF>
+__device__ __forceinline__ void gn_flush(const GP& p, GnAcc<NF>& a, long long sid, long long nw0, int lane, unsigned char* stage, unsigned slot) {
+    float* sf = reinterpret_cast<float*>(stage);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        f32x4 t = {a.s[j][0], a.s[j][1], a.q[j][0], a.q[j][1]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = t[e];
+            v += dpp_row_shr<1>(v);
+            v += dpp_row_shr<2>(v);
+            v += dpp_row_shr<4>(v);
+            v += dpp_row_shr<8>(v);     // lane 15 of each row: the row's total
+            t[e] = v;
+        }
+        // 4 lanes: channel pairs of channels j * 16 + (lane >> 4) * 4 .. + 3 of the wave tile, as {s01, s23, q01, q23}
+        if ((lane & 15) == 15) lds_store16_nowait(sf + (j * 4 + (lane >> 4)) * 4, t);
+    }
+    // one lane per GroupNorm group that intersects the wave tile's channels [nw0, nw0 + NF * 16)
+    const int cpg = p.gn_cpg;
+    const int g_lo = (int)(nw0 / cpg), g_hi = (int)((nw0 + NF * 16 - 1) / cpg);
+    const int g = g_lo + lane;
+    if (g <= g_hi) {
+        const int c0 = g * cpg > (int)nw0 ? g * cpg - (int)nw0 : 0;
+        const int c1 = (g + 1) * cpg - (int)nw0 < NF * 16 ? (g + 1) * cpg - (int)nw0 : NF * 16;
+        float sa = 0.f, sb = 0.f;
+        for (int cp = c0 >> 1; cp < (c1 >> 1); ++cp) {            // channel pair cp = channels 2 cp, 2 cp + 1 of the tile
+            const float* e = sf + (cp >> 1) * 4 + (cp & 1);
+            sa += e[0];
+            sb += e[2];
+        }
+        float* dst = p.gn_stats + ((sid * V3D_GN_SLOTS + slot) * 32 + g) * 2;
+        if (!(p.ablate & 1024)) {
+            atomicAdd(dst, sa);
+            atomicAdd(dst + 1, sb);
+        }
+    }
+    gn_zero(a);
+}
+
+template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false, int SPAD = 16, bool GN = false>
 __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
                                          unsigned char* stage, u32x4 pre0, u32x4 pre1, u32x4 pre2, bool res_pre,
-                                         const float4 (&bias_pre)[NF], bool has_bias_pre) {
+                                         const float4 (&bias_pre)[NF], bool has_bias_pre, GnAcc<GN ? NF : 1>* gn = nullptr) {
     if (p.ablate & 1) {
         float sum = 0.f;
 #pragma unroll
@@ -337,8 +407,12 @@ __device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long
                 if (of) {
                     *reinterpret_cast<float4*>(of + jo * 16) = make_float4(o[0], o[1], o[2], o[3]);
                 } else if (CAN_STAGE) {
-                    *reinterpret_cast<uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2) =
-                        make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                    const uint32_t w0 = pack2bf(o[0], o[1]), w1 = pack2bf(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2) = make_uint2(w0, w1);
+                    if constexpr (GN) {
+                        gn_add_pair(gn->s[j][0], gn->q[j][0], w0);
+                        gn_add_pair(gn->s[j][1], gn->q[j][1], w1);
+                    }
                 }
             }
         }
@@ -704,9 +778,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
 // retire the finished tile of a v3 wave in chunks of EMF row fragments; residual rows come in one chunk ahead of their use
 // (a per-chunk load -> LDS -> use chain exposed the full load latency 8 times per tile: the [bar] out-projections ran
 // 15-50 % slower than on v2)
-template <int C, int NCH, int EMF, int NF, bool GEGLU, int SPAD>
+template <int C, int NCH, int EMF, int NF, bool GEGLU, int SPAD, bool GN>
 __device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH * EMF][NF], long long mw0, long long nw0, int lane, unsigned char* estage,
-                                                 u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre, const float4 (&bv)[NF]) {
+                                                 u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre, const float4 (&bv)[NF], GnAcc<GN ? NF : 1>& gn,
+                                                 long long sid0, unsigned rem0) {
     static_assert(ResGeom<EMF, NF, GEGLU>::NV <= 3, "v3 epilogue chunk: at most 3 residual pieces per lane");
     if constexpr (C < NCH) {
         u32x4 n0 = c0, n1 = c1, n2 = c2;
@@ -717,15 +792,23 @@ __device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH *
                 n2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
             }
         }
-        epilogue<EMF, NF, GEGLU, true, true, SPAD>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true);
-        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU, SPAD>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre, bv);
+        epilogue<EMF, NF, GEGLU, true, true, SPAD, GN>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true, &gn);
+        if constexpr (GN) {
+            // rows of this chunk belong to statistics group sid0 + (rem0 + C * 16) / gn_rps; hand the sums over when the next chunk
+            // starts another group (a tile may straddle images: 4096 rows per image, 96 per wave tile) or the tile ends
+            static_assert(EMF == 1, "GN epilogue: one row fragment per chunk");
+            const unsigned rps = (unsigned)p.gn_rps;
+            const unsigned here = (rem0 + C * 16) / rps, next = (rem0 + (C + 1) * 16) / rps;
+            if (C + 1 == NCH || next != here) gn_flush<NF>(p, gn, sid0 + here, nw0, lane, estage, (unsigned)((mw0 >> 4) + C + (nw0 >> 4)) % V3D_GN_SLOTS);
+        }
+        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU, SPAD, GN>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre, bv, gn, sid0, rem0);
     }
 }
 
 // slot-level timeline of the v3 loop (V3D_GEMM_ABLATE bit 8, LINEAR only): [group][step 32..63][stamp] s_memtime ticks
 __device__ unsigned long long g_v3_dbg[2 * 32 * 8];
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool GEGLU, int EMF, bool DBG = false, int NS = 4, int SPAD = 16>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool GEGLU, int EMF, bool DBG = false, int NS = 4, int SPAD = 16, bool GN = false>
 __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int ntiles) {   // (HIP: 2nd arg = min waves per SIMD)
     // NS = 4: one block per CU (128 KiB ring).  NS = 3 with a 256 x 128 tile: 72 KiB ring + 8 KiB staging = 80 KiB -> TWO blocks per
     // CU (128 VGPRs per wave), so one block's VALU-bound epilogue (GEGLU) overlaps the other block's main loop.
@@ -929,7 +1012,15 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
 #pragma unroll
             for (int j = 0; j < NF; ++j)
                 bv[j] = (p.bias && inside) ? *reinterpret_cast<const float4*>(p.bias + (int)nw0 + (lane >> 4) * 4 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v3_retire_chunks<0, MF / EMF, EMF, NF, GEGLU, SPAD>(p, acc, mw0, nw0, lane, estage, r0, r1, r2, res_pre, bv);
+            GnAcc<GN ? NF : 1> gn;
+            long long sid0 = 0;
+            unsigned rem0 = 0;
+            if constexpr (GN) {
+                gn_zero(gn);
+                sid0 = mw0 / p.gn_rps;
+                rem0 = (unsigned)(mw0 - sid0 * p.gn_rps);
+            }
+            if (!GN || inside) v3_retire_chunks<0, MF / EMF, EMF, NF, GEGLU, SPAD, GN>(p, acc, mw0, nw0, lane, estage, r0, r1, r2, res_pre, bv, gn, sid0, rem0);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -1177,6 +1268,10 @@ int v3s_choice() {
     return v;
 }
 
+// set by launch_v3 when the launch it made gathers GroupNorm statistics in its epilogue (else v3d_gemm runs the stand-alone kernel)
+thread_local bool g_gn_in_epilogue = false;
+long long g_gn_epilogue_launches = 0;      // (tests: how many launches of this process gathered the statistics in their epilogue)
+
 template <int MODE, bool GEGLU>
 int launch_v3(const GP& p0, hipStream_t st, int variant) {
     GP p = p0;
@@ -1200,7 +1295,19 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
     }
     if constexpr (!GEGLU) {
         if (variant == 1) {   // the N = 320 family: 192 x 320 tile, wave tile 96 x 80 (147456 rows = 768 tiles = 3 per CU)
-            hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            if (p.gn_stats) {
+                g_gn_in_epilogue = true;
+                ++g_gn_epilogue_launches;
+                hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            } else {
+                hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            }
+            return v3d_check_launch("v3d_gemm");
+        }
+        if (p.gn_stats) {
+            g_gn_in_epilogue = true;
+            ++g_gn_epilogue_launches;
+            hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
     }
@@ -1252,9 +1359,16 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
 
 }  // namespace
 
+// tests only (not part of the ABI header)
+extern "C" long long v3d_debug_gn_epilogue_launches(void) { return g_gn_epilogue_launches; }
+
 // experiments only (not part of the ABI header): copy the v3 slot timeline out
 extern "C" int v3d_debug_v3_timeline(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v3_dbg), sizeof(g_v3_dbg)) == hipSuccess ? 0 : -1;
+}
+
+namespace {
+int run_mode(const v3d_gemm_args* a, GP& p, hipStream_t st);
 }
 
 extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
@@ -1305,6 +1419,26 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     p.ws = nullptr;
     { static int ab = -1; if (ab < 0) { const char* e = getenv("V3D_GEMM_ABLATE"); ab = e ? atoi(e) : 0; } p.ablate = ab; }
     hipStream_t st = (hipStream_t)stream;
+    p.gn_stats = nullptr; p.gn_rps = 0; p.gn_cpg = 0;
+    if (a->gn_stats) {
+        V3D_REQUIRE(!a->geglu && !a->out_fp32 && a->batch == 1, "v3d_gemm: gn_stats needs a bf16, non-GEGLU, unbatched output");
+        V3D_REQUIRE(a->gn_cpg > 0 && a->gn_cpg % 2 == 0 && a->N == 32ll * a->gn_cpg, "v3d_gemm: gn_stats needs N = 32 * gn_cpg (got N=%lld cpg=%d)", (long long)a->N, a->gn_cpg);
+        V3D_REQUIRE(a->gn_rps >= 16 && a->gn_rps % 16 == 0 && a->gn_rps < (1ll << 30) && a->M % a->gn_rps == 0, "v3d_gemm: gn_rps must be a multiple of 16 that divides M");
+        V3D_REQUIRE(a->ldo == a->N && ((uintptr_t)a->gn_stats & 3) == 0, "v3d_gemm: gn_stats needs a dense output (ldo == N)");
+        static int ep = -1;
+        if (ep < 0) { const char* e = getenv("V3D_GEMM_GN_EPILOGUE"); ep = e ? atoi(e) : 1; }      // A/B knob: 0 = always the stand-alone statistics kernel
+        if (ep) { p.gn_stats = a->gn_stats; p.gn_rps = a->gn_rps; p.gn_cpg = a->gn_cpg; }
+        g_gn_in_epilogue = false;
+        const int rc = run_mode(a, p, st);
+        if (rc != V3D_OK || g_gn_in_epilogue) return rc;
+        // the kernel that ran has no statistics epilogue (v1 / v2 tiles, split-K, ragged shapes): same result from the stand-alone kernel
+        return v3d_groupnorm_stats(a->out, a->N, nullptr, 0, a->gn_stats, a->M / a->gn_rps, a->gn_rps, 32, 1, stream);
+    }
+    return run_mode(a, p, st);
+}
+
+namespace {
+int run_mode(const v3d_gemm_args* a, GP& p, hipStream_t st) {
     switch (a->mode) {
         case V3D_GEMM_LINEAR:
             if (a->geglu) return dispatch<V3D_GEMM_LINEAR, true>(p, a->batch, st);
@@ -1332,3 +1466,4 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
             return V3D_ERR_ARG;
     }
 }
+}  // namespace

@@ -14,7 +14,7 @@ import torch
 from .ops import GemmCall, OpsBase
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libv3d_hip.so")
+LIB_PATH = os.environ.get("V3D_HIP_LIB") or os.path.join(_HERE, "lib", "libv3d_hip.so")     # (override: A/B runs of two builds on one box)
 
 ABI_VERSION = 3
 
