@@ -181,7 +181,14 @@ class _Timed:
         def m_ln(x, gamma, beta, out, eps, add=None, add_rpg=0, add_ld=0, xsum_out=None):
             return "layernorm", 0.0, (3 if xsum_out is not None else 2) * x.numel() * 2
 
+        def m_lnp(x, eps, wp, bias, n_rm, S):
+            # LayerNorm + q | k | v projection in one launch (proj.hip): the GEMM's flops; bytes = token rows, weights and outputs once
+            M, C, N = x.shape[0], x.shape[1], wp.shape[0]
+            return "gemm_ln_proj", 2.0 * M * N * C, M * C * 2 + N * C * 2 + M * N * 2
+
         self._wrap("gemm", m_gemm)
+        if hasattr(self.ops, "ln_proj"):
+            self._wrap("ln_proj", m_lnp)
         if hasattr(self.ops, "ff_fused"):
             self._wrap("ff_fused", m_ff)
         self._wrap("attn_spatial", m_attn)
@@ -243,7 +250,7 @@ def measure_rooflines(step):
                  "kernels_changed_since": pmc.get("csrc_sha256_16") != csrc_digest()}
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3 / v2 (conv3x3 / convt3 / linear / GEGLU launches) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards)",
+    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3 / v2 (conv3x3 / convt3 / linear / GEGLU launches, incl. the GroupNorm-statistics epilogue of the 3x3 convolutions) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards) + ln_proj_kernel<320> (LayerNorm + q|k|v projection)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC passes)", "traffic_profile": tinfo,
             "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2),
