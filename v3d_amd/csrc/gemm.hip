@@ -889,7 +889,10 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     auto issue_piece = [&](int stage, int i) __attribute__((always_inline)) {
         if (p.ablate & 4) return;
         const int q = wave + NW * i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)voff[i], ld_k0 * 2, 0, 0);
+        // experiment (bit 2048): activation pieces issued out of range - same DMA op count, zeros instead of an L2 fetch: what the L2->LDS bytes
+        // of the activation operand cost (a lower bound of what an LDS-resident halo tile would save a 3x3 convolution)
+        const unsigned vo = ((p.ablate & 2048) && q < APIECES) ? kInvalid : voff[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)vo, ld_k0 * 2, 0, 0);
     };
     auto issue_advance = [&]() __attribute__((always_inline)) {
         if (ntaps<MODE>() > 1 && p.tap_inner) {   // (k outer, tap inner), see the v2 loader
