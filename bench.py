@@ -378,6 +378,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-rollout", action="store_true")
+    ap.add_argument("--shard-timeout", dest="shard_timeout", type=float, default=240.0,
+                    help="N > 1 replica mode: seconds the secondary frame-sharded run may take before the line is printed without it")
     ap.add_argument("--graph", action="store_true",
                     help="replay captured HIP graphs of the network evaluation / decode instead of launching from Python "
                          "(measured 9.59 vs 9.62 frames/s: ROCm 7.2 graph replay does not close the launch gaps, so it is off by default)")
@@ -451,8 +453,30 @@ def main():
             "achieved_tflops_reference_graph": round(samples * sample_tflop / dt, 1),
             "frac_of_bf16_peak_reference_graph": round(samples * sample_tflop / dt / PEAK_BF16_TFLOPS / world, 4),
         }
-    # ---- N > 1, replica mode: the frame-sharded (latency) mode of the same job, measured after the timed region ----
+    if rank == 0 and not args.no_roofline:
+        # per-launch HIP events need the launches to come from Python: the instrumented sample runs un-captured (and un-sharded)
+        noise0, c0, uc0 = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23, device=device)
+        result["roofline"] = measure_rooflines(make_step(wrapped, dec, sampler, denoiser, noise0, c0, uc0, device, graph=False))
+        result["config"]["hip_graph"] = bool(args.graph)
+    if world > 1:
+        dist.barrier()
+    # ---- N > 1, replica mode: the frame-sharded (latency) mode of the same job, measured LAST and under a watchdog: it is a secondary
+    #      number and its exchanges (grouped RCCL P2P between all ranks) must never cost the run its replica result - if it has not
+    #      finished in time, rank 0 prints the line it has and every rank leaves without waiting for the others ----
+    printed = [False]
     if world > 1 and not shard_mode:
+        import threading
+
+        def bail():
+            if rank == 0 and not printed[0]:
+                result["frame_shard"] = {"value": None, "error": f"frame-sharded secondary run did not finish within {args.shard_timeout} s (abandoned)"}
+                printed[0] = True
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.shard_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         fs = None
         try:
             n_fs = max(1, min(args.steps, 3))
@@ -467,15 +491,16 @@ def main():
                   "note": "ONE sample, frames sharded over the ranks for all 25 steps + decode (v3d_amd/dist.py::sharded_sample); not part of `value`"}
         except Exception as e:   # never lose the replica number to the secondary measurement
             fs = {"value": None, "error": f"{type(e).__name__}: {e}"[:400]}
-        if rank == 0:
+        if rank == 0 and not printed[0]:
             result["frame_shard"] = fs
-    if rank == 0 and not args.no_roofline:
-        # per-launch HIP events need the launches to come from Python: the instrumented sample runs un-captured (and un-sharded)
-        noise0, c0, uc0 = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23, device=device)
-        result["roofline"] = measure_rooflines(make_step(wrapped, dec, sampler, denoiser, noise0, c0, uc0, device, graph=False))
-        result["config"]["hip_graph"] = bool(args.graph)
-    if world > 1:
-        dist.barrier()
+            printed[0] = True
+            print(json.dumps(result), flush=True)
+        try:                      # (a rank that failed alone would wait here for ever: the watchdog is still armed)
+            dist.barrier()
+            dist.destroy_process_group()
+        finally:
+            watchdog.cancel()
+        return
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(unet, dec)
