@@ -124,6 +124,15 @@ int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const float* b1, c
                  const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
                  float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,
                  v3d_stream_t stream);
+
+/* LayerNorm + the same feed-forward in ONE launch - BasicTransformerBlock `x = ff(norm3(x)) + x` (sgm/modules/attention.py:575-577) and the
+ * VideoTransformerBlock's `norm3 / ff` (video_attention.py:133-140): the rows are normalised in registers, out = ... W1 ((x[m] - mean) * rstd)
+ * with the LayerNorm affine folded into the weights by the caller: W1 <- W1 diag(gamma), b1 <- b1 + W1 beta BEFORE the packing above
+ * (v3d_amd/engine/packing.py ff_fused_pack(..., ln=(gamma, beta))).  res1 is normally x itself.  ln_eps > 0.  Same shape rules. */
+int v3d_ln_ff_fused(const void* x, int64_t ldx, float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                 const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
+                 float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,
+                 v3d_stream_t stream);
 /* LayerNorm + q | k | v projection of a transformer block in one kernel (ABI 3; C = 320, the 64x64 level).  Reference:
  * BasicTransformerBlock / VideoTransformerBlock x -> norm1(x) -> attn1.to_q / to_k / to_v (sgm/modules/attention.py:556-563,286-290;
  * sgm/modules/video_attention.py:122-125; the three Linears have no bias).  The LayerNorm affine is folded through the projection at pack time

@@ -278,6 +278,11 @@ class EmulOps(OpsBase):
         logical = torch.gather(t, 5, pos)                                            # [.., row, chunk, 8]
         return logical.permute(0, 3, 4, 1, 2, 5, 6).reshape(rows, cols)
 
+    def ln_ff_fused(self, x, eps, w1p, b1, w2p, b2, out, **kw):
+        """v3d_ln_ff_fused: rows normalised without affine (it is folded into w1p / b1), rounded where the kernel rounds them, then ff_fused."""
+        xh = F.layer_norm(x.float(), (x.shape[-1],), None, None, eps).to(self.act_dtype)
+        return self.ff_fused(xh, w1p, b1, w2p, b2, out, **kw)
+
     def ff_fused(self, x, w1p, b1, w2p, b2, out, *, res1=None, res2=None, coef=None, coef_rpg=0, c_acc=1.0, c_res1=1.0, c_res2=1.0):
         M, Cc = x.shape
         hidden = w2p.shape[-1]

@@ -100,10 +100,13 @@ def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=Tru
     return compare(out_h, out_e)
 
 
-def case_ff_fused(hip, emu, dev, *, M, C=320, hidden=1280, res=1, coef=False, seed=0):
-    """v3d_ff_fused (GEGLU feed-forward, hidden tensor on chip) against its emulation (= two emulated GEMMs with the same packing)."""
+def case_ff_fused(hip, emu, dev, *, M, C=320, hidden=1280, res=1, coef=False, seed=0, ln=False):
+    """v3d_ff_fused (GEGLU feed-forward, hidden tensor on chip) against its emulation (= two emulated GEMMs with the same packing).
+    ln: v3d_ln_ff_fused - LayerNorm of the (non-zero-mean) rows inside the kernel, against layer_norm -> bf16 -> the same emulation."""
     g = torch.Generator().manual_seed(seed)
     x = _rand(g, (M, C), device=dev)
+    if ln:
+        x = (x.float() * 1.5 + 0.3).to(BF)
     w1 = _rand(g, (2 * hidden, C), scale=1 / math.sqrt(C), device=dev)
     b1 = _rand(g, (2 * hidden,), F32, 0.5, dev)
     w2 = _rand(g, (C, hidden), scale=1 / math.sqrt(hidden), device=dev)
@@ -119,6 +122,10 @@ def case_ff_fused(hip, emu, dev, *, M, C=320, hidden=1280, res=1, coef=False, se
         kw.update(coef=_rand(g, ((M + rpg - 1) // rpg, 3), F32, 1.0, dev), coef_rpg=rpg)
     o_h = torch.zeros((M, C), dtype=BF, device=dev)
     o_e = torch.zeros((M, C), dtype=BF, device=dev)
+    if ln:
+        hip.ln_ff_fused(x, 1e-5, w1, b1, w2, b2, o_h, **kw)
+        emu.ln_ff_fused(x, 1e-5, w1, b1, w2, b2, o_e, **kw)
+        return compare(o_h, o_e)
     hip.ff_fused(x, w1, b1, w2, b2, o_h, **kw)
     emu.ff_fused(x, w1, b1, w2, b2, o_e, **kw)
     return compare(o_h, o_e)
@@ -358,6 +365,9 @@ def all_cases(full: bool = True):
         ("ff_fused_blend", case_ff_fused, dict(M=128 * 5, res=2, coef=True), TOL_BF16),
         ("ff_fused_plain_hidden256", case_ff_fused, dict(M=256, hidden=256, res=0), TOL_BF16),
         ("ff_fused_two_blocks_per_cu", case_ff_fused, dict(M=128 * 300, res=1, seed=3), TOL_BF16),
+        ("ln_ff_fused_res1", case_ff_fused, dict(M=384, res=1, ln=True, seed=4), TOL_BF16),
+        ("ln_ff_fused_blend", case_ff_fused, dict(M=128 * 5, res=2, coef=True, ln=True, seed=5), TOL_BF16),
+        ("ln_ff_fused_many_blocks", case_ff_fused, dict(M=128 * 600, res=1, ln=True, seed=6), TOL_BF16),
         ("gemm_batched_perbatchW", case_gemm, dict(M=128, N=128, K=512, batch=2, bias=False, shared_w=False, out_fp32=True), TOL_BF16),
         ("conv3x3_small", case_gemm, dict(M=0, N=64, K=32, mode=C3, conv=(2, 8, 8, 1, 1)), TOL_BF16),
         ("conv3x3_odd_hw", case_gemm, dict(M=0, N=40, K=24, mode=C3, conv=(3, 7, 5, 1, 1), add=True, res=1), TOL_BF16),

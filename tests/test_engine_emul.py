@@ -170,3 +170,28 @@ def test_ln_proj_path_equals_unfused_path(monkeypatch):
         b = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
     rel, cos = rel_cos(a, b)
     assert rel <= 1e-5 and cos >= 0.999999, (rel, cos)
+
+
+def test_ln_ff_fused_path_equals_unfused_path(monkeypatch):
+    """norm3 + feed-forward in one launch (v3d_ln_ff_fused: LayerNorm affine folded into the first Linear at pack time, rows normalised inside
+    the kernel) against v3d_layernorm -> v3d_ff_fused, on a one-level width-320 network with exact-fp32 emulated kernels."""
+    from v3d_amd import synth
+    from v3d_amd.engine import unet as unet_engine
+    from v3d_amd.sgm.modules.diffusionmodules.video_model import VideoUNet
+    cfg = dict(synth.unet_config(320), channel_mult=[1], num_res_blocks=1, attention_resolutions=[1])
+    T, H, W = 2, 8, 16
+    g = torch.Generator().manual_seed(6)
+    n = 2 * T
+    x8, ts = torch.randn(n, 8, H, W, generator=g), torch.randn(n, generator=g)
+    ctx, y = torch.randn(n, 1, 1024, generator=g), torch.randn(n, 768, generator=g)
+    with use_backend(EmulOps("cpu", exact=True)):
+        net = VideoUNet(**cfg).eval()
+        net.load_state_dict(synth.seeded_state_dict(net, 22))
+        svt = net.packed().input_stages[1][1][1]
+        assert svt.s_ff.w1_ln_fused is not None and svt.t_ff.w1_ln_fused is not None and svt.t_ff_in.w1_ln_fused is None
+        monkeypatch.setattr(unet_engine, "_LN_FF", True)
+        a = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+        monkeypatch.setattr(unet_engine, "_LN_FF", False)
+        b = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+    rel, cos = rel_cos(a, b)
+    assert rel <= 1e-5 and cos >= 0.999999, (rel, cos)

@@ -53,6 +53,48 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// LayerNorm (no affine) of a wave's 32 rows held as MFMA operand fragments, in place: lane (l31 = lane & 31, hi = lane >> 5) holds channels
+// 16 k + 8 hi .. + 7 of row l31 in xr[k], its partner lane (lane ^ 32) the rest.  gamma / beta are folded into the consumer's weights / bias at
+// pack time (W diag(gamma), W beta), so this is (x - mean) * rstd only.  Sums and sums of squares by v_dot2_f32_bf16 on the packed pairs (1
+// instruction per 2 elements, exact bf16 products, fp32 accumulation); variance as E[x^2] - mean^2 in fp32; the result is rounded to bf16 where
+// the stand-alone v3d_layernorm stores it.  (Element pairs are picked with shufflevector: the u32x4 bit_cast + subscript form of the first loop
+// was miscompiled by ROCm 7.2's clang - every dot2 read dword 0 of the fragment.)
+template <int NK>
+__device__ __forceinline__ void ln_rows_inplace(bf16x8 (&xr)[NK], float eps) {
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    constexpr int C = NK * 16;
+    const bf16x2v ones = __builtin_bit_cast(bf16x2v, 0x3f803f80u);
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const bf16x2v a = __builtin_shufflevector(xr[k], xr[k], 0, 1), b = __builtin_shufflevector(xr[k], xr[k], 2, 3);
+        const bf16x2v c = __builtin_shufflevector(xr[k], xr[k], 4, 5), d = __builtin_shufflevector(xr[k], xr[k], 6, 7);
+        s0 = __builtin_amdgcn_fdot2_f32_bf16(a, ones, s0, false);
+        s1 = __builtin_amdgcn_fdot2_f32_bf16(b, ones, s1, false);
+        q0 = __builtin_amdgcn_fdot2_f32_bf16(a, a, q0, false);
+        q1 = __builtin_amdgcn_fdot2_f32_bf16(b, b, q1, false);
+        s0 = __builtin_amdgcn_fdot2_f32_bf16(c, ones, s0, false);
+        s1 = __builtin_amdgcn_fdot2_f32_bf16(d, ones, s1, false);
+        q0 = __builtin_amdgcn_fdot2_f32_bf16(c, c, q0, false);
+        q1 = __builtin_amdgcn_fdot2_f32_bf16(d, d, q1, false);
+    }
+    float s = s0 + s1, q = q0 + q1;
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float mean = s * (1.0f / C);
+    const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float sh = -mean * rstd;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const u32x4 u = __builtin_bit_cast(u32x4, xr[k]);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(__builtin_fmaf(bflo(u[e]), rstd, sh), __builtin_fmaf(bfhi(u[e]), rstd, sh));
+        xr[k] = __builtin_bit_cast(bf16x8, o);
+    }
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (F.gelu default, reference attention.py:97-99) with erf from Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, far below bf16 resolution): 1 rcp + 1 exp + 6 fma instead of libm erff's ~40 instructions —

@@ -60,6 +60,7 @@ struct FFP {
     long long M, ldx, ldr1, ldr2, ldo, coef_rpg;
     float c_acc, c_res1, c_res2;
     int hidden;
+    float ln_eps;        // <LN> kernels: LayerNorm (no affine) of the input rows in registers before the first GEMM
     unsigned w1_bytes, w2_bytes;
     int stagger_long, stagger_short, n_long;   // start delays (s_sleep units) spread over the CUs with one block more / less
 };
@@ -94,7 +95,7 @@ __device__ __forceinline__ int ff_swz(int row) { return (0x78 >> (((row >> 2) & 
 
 __device__ unsigned long long g_ff_dbg[4 * 16 * 8 + 4 * 4 * 8];   // [wave][tick 8..23][stamp] of block 0, then [wave][block 0..3][phase] (timeline build only)
 
-template <int C, bool DBG = false>
+template <int C, bool DBG = false, bool LN = false>
 __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     constexpr int NT = C / 32;                 // 32-k LDS stages of a W1 slab
     constexpr int NK = C / 16;                 // k16 steps of stage A = resident x fragments
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     w2_wr_slot = 1;
     load_x(blk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (LN) ln_rows_inplace<NK>(xr, p.ln_eps);
     __builtin_amdgcn_s_barrier();
     tick(I0{}, IX{}, IX{}, IX{}, I0{}, I0{}, -1);
 
@@ -450,6 +452,8 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
         bstamp(2);
         load_x(nxt < nblocks ? nxt : blk);
         tick(IX{}, I1{}, I0{}, I1{}, I0{}, I1{}, nslab - 1);   // G(last) B(last-1)    DMA W1'(1)
+        // <LN>: the block's LayerNorm on the freshly loaded rows (their load latency went under the tick above); ~170 VALU per block
+        if constexpr (LN) ln_rows_inplace<NK>(xr, p.ln_eps);
         bstamp(3);
         fetch_res(mw0, 0, r1[0], r2[0]);                   // the epilogue's first pass: in flight under the boundary tick
         tick(I0{}, IX{}, I1{}, IX{}, I1{}, I0{}, nslab);   // A'(0) B(last)        DMA W2'(0)
@@ -526,10 +530,10 @@ extern "C" int v3d_debug_ff_timeline(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ff_dbg), sizeof(g_ff_dbg)) == hipSuccess ? 0 : -1;
 }
 
-extern "C" int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
-                            const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
-                            float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,
-                            v3d_stream_t stream) {
+static int ff_fused_launch(const void* x, int64_t ldx, float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                           const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
+                           float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,
+                           v3d_stream_t stream) {
     V3D_REQUIRE(x && W1p && b1 && W2p && b2 && out, "v3d_ff_fused: null pointer");
     V3D_REQUIRE(C == 320, "v3d_ff_fused: built for C = 320 (got %d); wider levels use the two-GEMM path", C);
     V3D_REQUIRE(hidden >= 128 && hidden % 64 == 0 && hidden * (long long)C * 4 < (1ll << 31), "v3d_ff_fused: bad hidden size %d", hidden);
@@ -543,7 +547,7 @@ extern "C" int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const f
     p.x = (const bf16_t*)x; p.W1 = (const bf16_t*)W1p; p.W2 = (const bf16_t*)W2p; p.b1 = b1; p.b2 = b2;
     p.res1 = (const bf16_t*)res1; p.res2 = (const bf16_t*)res2; p.coef = coef; p.out = (bf16_t*)out;
     p.M = M; p.ldx = ldx; p.ldr1 = ldr1; p.ldr2 = ldr2; p.ldo = ldo; p.coef_rpg = coef_rpg;
-    p.c_acc = c_acc; p.c_res1 = c_res1; p.c_res2 = c_res2; p.hidden = hidden;
+    p.c_acc = c_acc; p.c_res1 = c_res1; p.c_res2 = c_res2; p.hidden = hidden; p.ln_eps = ln_eps;
     p.w1_bytes = (unsigned)(2ll * hidden * C * 2);
     p.w2_bytes = (unsigned)((long long)C * hidden * 2);
     const long long nblocks = M / 128;
@@ -563,9 +567,26 @@ extern "C" int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const f
         p.stagger_short = rem ? stagger * hidden / 1280 : 0;
         p.stagger_long = p.stagger_long * hidden / 1280;
     }
-    if (dbg)
+    if (ln_eps > 0.f)
+        hipLaunchKernelGGL((ff_fused_kernel<320, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (dbg)
         hipLaunchKernelGGL((ff_fused_kernel<320, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((ff_fused_kernel<320>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return v3d_check_launch("v3d_ff_fused");
+}
+
+extern "C" int v3d_ff_fused(const void* x, int64_t ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                            const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
+                            float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,
+                            v3d_stream_t stream) {
+    return ff_fused_launch(x, ldx, 0.f, W1p, b1, W2p, b2, res1, ldr1, res2, ldr2, coef, coef_rpg, c_acc, c_res1, c_res2, out, ldo, M, C, hidden, stream);
+}
+
+extern "C" int v3d_ln_ff_fused(const void* x, int64_t ldx, float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                               const void* res1, int64_t ldr1, const void* res2, int64_t ldr2, const float* coef, int64_t coef_rpg,
+                               float c_acc, float c_res1, float c_res2, void* out, int64_t ldo, int64_t M, int32_t C, int32_t hidden,
+                               v3d_stream_t stream) {
+    V3D_REQUIRE(ln_eps > 0.f, "v3d_ln_ff_fused: ln_eps must be > 0");
+    return ff_fused_launch(x, ldx, ln_eps, W1p, b1, W2p, b2, res1, ldr1, res2, ldr2, coef, coef_rpg, c_acc, c_res1, c_res2, out, ldo, M, C, hidden, stream);
 }

@@ -118,48 +118,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
             for (int k = 0; k < NK; ++k) xr[r][k] = *reinterpret_cast<const bf16x8*>(xz + k * 16);
         }
     };
-    // LayerNorm of the wave's rows in place: lane (l31, hi) holds channels 16 k + 8 hi .. + 7 of row r * 32 + l31, its partner lane the rest.
-    // gamma and beta are folded into the weights / the output bias at pack time (W diag(gamma), W beta), so this is (x - mean) * rstd only.
-    // Sums and sums of squares by v_dot2_f32_bf16 on the packed pairs (1 instruction per 2 elements, exact bf16 products, fp32 accumulation)
-    // instead of unpack + add / fma; variance as E[x^2] - mean^2 in fp32 (the first version: 3 unpacking passes + gamma / beta from LDS =
-    // 37k cycles per block).
-    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    // LayerNorm of the wave's rows in place (common.h ln_rows_inplace: dot2 statistics, gamma / beta folded into the weights / the output bias)
     auto normalise = [&]() __attribute__((always_inline)) {
-        const bf16x2v ones = __builtin_bit_cast(bf16x2v, 0x3f803f80u);
 #pragma unroll
-        for (int r = 0; r < RF; ++r) {
-            float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                // (element pairs picked with shufflevector: the u32x4 bit_cast + subscript form of this loop was miscompiled by ROCm 7.2's
-                //  clang - every dot2 read dword 0 of the fragment)
-                const bf16x2v a = __builtin_shufflevector(xr[r][k], xr[r][k], 0, 1), b = __builtin_shufflevector(xr[r][k], xr[r][k], 2, 3);
-                const bf16x2v c = __builtin_shufflevector(xr[r][k], xr[r][k], 4, 5), d = __builtin_shufflevector(xr[r][k], xr[r][k], 6, 7);
-                s0 = __builtin_amdgcn_fdot2_f32_bf16(a, ones, s0, false);
-                s1 = __builtin_amdgcn_fdot2_f32_bf16(b, ones, s1, false);
-                q0 = __builtin_amdgcn_fdot2_f32_bf16(a, a, q0, false);
-                q1 = __builtin_amdgcn_fdot2_f32_bf16(b, b, q1, false);
-                s0 = __builtin_amdgcn_fdot2_f32_bf16(c, ones, s0, false);
-                s1 = __builtin_amdgcn_fdot2_f32_bf16(d, ones, s1, false);
-                q0 = __builtin_amdgcn_fdot2_f32_bf16(c, c, q0, false);
-                q1 = __builtin_amdgcn_fdot2_f32_bf16(d, d, q1, false);
-            }
-            float s = s0 + s1, q = q0 + q1;
-            s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 32, 64);
-            const float mean = s * (1.0f / C);
-            const float var = fmaxf(q * (1.0f / C) - mean * mean, 0.f);
-            const float rstd = rsqrtf(var + p.eps);
-            const float sh = -mean * rstd;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const u32x4 u = __builtin_bit_cast(u32x4, xr[r][k]);
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack2bf(__builtin_fmaf(bflo(u[e]), rstd, sh), __builtin_fmaf(bfhi(u[e]), rstd, sh));
-                xr[r][k] = __builtin_bit_cast(bf16x8, o);
-            }
-        }
+        for (int r = 0; r < RF; ++r) ln_rows_inplace<NK>(xr[r], p.eps);
     };
 
     // ---- output path of one slab tile, cut into the pieces the slab loop slots between its MFMAs

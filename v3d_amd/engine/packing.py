@@ -110,6 +110,10 @@ class FFPack:
     w1_fused: Optional[torch.Tensor] = None
     b1_fused: Optional[torch.Tensor] = None
     w2_fused: Optional[torch.Tensor] = None
+    # v3d_ln_ff_fused: the LayerNorm in front of the block folded into the first Linear (W1 diag(gamma), b1 + W1 beta), then the same packing
+    w1_ln_fused: Optional[torch.Tensor] = None
+    b1_ln_fused: Optional[torch.Tensor] = None
+    ln_eps: float = 0.0
 
 
 def ff_fused_row_order(hidden: int) -> torch.Tensor:
@@ -149,11 +153,16 @@ def ff_dma_tile_index(rows: int, cols: int, slab_rows: int, slab_cols: int) -> t
     return torch.cat(idx)
 
 
-def ff_fused_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
+def ff_fused_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, ln=None):
     """Linear(C, 2 hidden).weight / .bias and Linear(hidden, C).weight -> (W1p, b1p, W2p) of v3d_ff_fused: rows / columns in the
-    MFMA hand-over order (ff_fused_row_order / ff_fused_k_perm), then tiled into the DMA pieces of the kernel's weight stream."""
+    MFMA hand-over order (ff_fused_row_order / ff_fused_k_perm), then tiled into the DMA pieces of the kernel's weight stream.
+    ln = (gamma, beta) of a LayerNorm in front of the block (v3d_ln_ff_fused): LN(x) W1^T + b1 = xh (W1 diag(gamma))^T + (b1 + W1 beta)."""
     hidden = w2.shape[-1]
     C = w1.shape[1]
+    if ln is not None:
+        w1f = w1.detach().float()
+        b1 = b1.detach().float() + w1f @ ln[1].detach().float()
+        w1 = w1f * ln[0].detach().float()[None, :]
     ro = ff_fused_row_order(hidden).to(w1.device)
     w1p = w1[ro]                                                                  # [2 hidden, C]: slabs of 64 rows
     w2p = w2.reshape(-1, hidden)[:, ff_fused_k_perm(hidden).to(w2.device)]        # [C, hidden]:   slabs of 32 columns
@@ -227,7 +236,8 @@ class UNetPack:
     uses_ioi: bool
 
 
-def _pack_ff(ff) -> FFPack:
+def _pack_ff(ff, norm=None) -> FFPack:
+    """norm: the plain LayerNorm module whose output is this block's only input (norm3 of a transformer block) - folded for v3d_ln_ff_fused."""
     w1, b1 = pack_geglu(ff.net[0].proj)
     w2, b2 = pack_linear(ff.net[2])
     p = FFPack(w1, b1, w2, b2)
@@ -235,6 +245,10 @@ def _pack_ff(ff) -> FFPack:
     if C == 320 and hidden % 64 == 0 and hidden >= 128:
         lin1, lin2 = ff.net[0].proj, ff.net[2]
         p.w1_fused, p.b1_fused, p.w2_fused = ff_fused_pack(lin1.weight.detach(), lin1.bias.detach(), lin2.weight.detach())
+        if norm is not None:
+            p.w1_ln_fused, p.b1_ln_fused, _ = ff_fused_pack(lin1.weight.detach(), lin1.bias.detach(), lin2.weight.detach(),
+                                                             ln=(norm.weight, norm.bias))
+            p.ln_eps = float(norm.eps)
     return p
 
 
@@ -304,7 +318,7 @@ def pack_svt(st, col: _Collector) -> SVTPack:
     p.s_wo = pack_linear(blk.attn1.to_out[0])
     p.s_ctx_off = col.add_ctx(blk.attn2)
     p.s_norm3 = pack_norm(blk.norm3)
-    p.s_ff = _pack_ff(blk.ff)
+    p.s_ff = _pack_ff(blk.ff, blk.norm3)
     assert tb.ff_in is not False and tb.is_res
     p.t_norm_in = pack_norm(tb.norm_in)
     p.t_ff_in = _pack_ff(tb.ff_in)
@@ -314,7 +328,7 @@ def pack_svt(st, col: _Collector) -> SVTPack:
     assert tb.attn2 is not None, "disable_temporal_crossattention is not used by V3D/SVD"
     p.t_ctx_off = col.add_ctx(tb.attn2)
     p.t_norm3 = pack_norm(tb.norm3)
-    p.t_ff = _pack_ff(tb.ff)
+    p.t_ff = _pack_ff(tb.ff, tb.norm3)
     p.tpe = pack_linear(st.time_pos_embed[0]) + pack_linear(st.time_pos_embed[2])
     p.max_period = float(st.max_time_embed_period)
     p.mixer = col.add_mixer(st.time_mixer, 1)

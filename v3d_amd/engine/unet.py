@@ -82,10 +82,8 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
         ops.attn_spatial(qk[:, :C], qk[:, C:], vT, a, n, S, p.heads, 0.125)
     # x = attn1 + x, then attn2 (1 context token => a per-image vector, Appendix B-9) folded in the same epilogue
     x = ops.linear(a, p.s_wo[0], p.s_wo[1], res1=x, add=ctx[:, p.s_ctx_off:], add_rpg=S, add_ld=ctx_ld)
-    ga, be, eps = p.s_norm3
-    n3 = ops.empty((n * S, C), ops.act_dtype, x.device)
-    ops.layernorm(x, ga, be, n3, eps)
-    x_s = feed_forward(ops, n3, p.s_ff, res1=x)
+    # norm3 + ff: at the 64x64 level the LayerNorm runs inside the fused feed-forward (v3d_ln_ff_fused), else as its own launch
+    x_s = feed_forward(ops, x, p.s_ff, res1=x, ln=p.s_norm3)
 
     # ---- temporal VideoTransformerBlock on x_mix = x + frame embedding (video_attention.py:109-140,286-289) ----
     frames = range(T) if sh is None else sh.local_frames
@@ -119,24 +117,34 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     # (rows n.. of ctx_all hold the frame-0 projections, one per sample)
     x_t = ops.linear(ta.view(n * S, C), p.t_wo[0], p.t_wo[1], res1=x_t, add=ctx[n:, p.t_ctx_off:], add_rpg=S * T,
                      add_ld=ctx_ld)
-    ga, be, eps = p.t_norm3
-    ops.layernorm(x_t, ga, be, n3, eps)
-    # AlphaBlender fused: alpha * x_s + (1 - alpha) * (ff + x_t)
-    x = feed_forward(ops, n3, p.t_ff, res1=x_t, res2=x_s, coef=env.coefs[p.mixer], coef_rpg=S)
+    # AlphaBlender fused: alpha * x_s + (1 - alpha) * (ff(norm3(x_t)) + x_t)
+    x = feed_forward(ops, x_t, p.t_ff, res1=x_t, res2=x_s, coef=env.coefs[p.mixer], coef_rpg=S, ln=p.t_norm3)
     return ops.linear(x, p.proj_out[0], p.proj_out[1], res1=x_in)
 
 
 _FF_FUSED = os.environ.get("V3D_FF_FUSED", "1") not in ("", "0")
+_LN_FF = os.environ.get("V3D_LN_FF", "1") not in ("", "0")      # A/B knob: 0 = LayerNorm as its own launch in front of v3d_ff_fused
 
 
-def feed_forward(ops, xin, ff, *, res1, res2=None, coef=None, coef_rpg=0):
+def feed_forward(ops, xin, ff, *, res1, res2=None, coef=None, coef_rpg=0, ln=None):
     """FeedForward with GEGLU (attention.py:82-113): out = W2 (value * gelu(gate)) + b2 + residual(s).  At C = 320 (the 64x64 level)
-    one fused kernel keeps the 4x-wide hidden tensor on the CU (v3d_ff_fused); elsewhere two v3d_gemm launches."""
+    one fused kernel keeps the 4x-wide hidden tensor on the CU (v3d_ff_fused); elsewhere two v3d_gemm launches.
+    ln = (gamma, beta, eps): `xin` is the input of the LayerNorm in front of the block (norm3) - normalised inside the fused kernel where it
+    exists (v3d_ln_ff_fused, the rows are register-resident there anyway), by v3d_layernorm otherwise."""
     M, C = xin.shape
     kw = dict(res1=res1)
     if res2 is not None:
         kw.update(res2=res2, coef=coef, coef_rpg=coef_rpg)
-    if _FF_FUSED and ff.w2_fused is not None and M % 128 == 0 and hasattr(ops, "ff_fused"):
+    fused = _FF_FUSED and ff.w2_fused is not None and M % 128 == 0 and hasattr(ops, "ff_fused")
+    if ln is not None:
+        if fused and _LN_FF and ff.w1_ln_fused is not None and hasattr(ops, "ln_ff_fused"):
+            out = ops.empty((M, C), ops.act_dtype, xin.device)
+            return ops.ln_ff_fused(xin, ff.ln_eps, ff.w1_ln_fused, ff.b1_ln_fused, ff.w2_fused, ff.b2, out, **kw)
+        ga, be, eps = ln
+        normed = ops.empty((M, C), ops.act_dtype, xin.device)
+        ops.layernorm(xin, ga, be, normed, eps)
+        xin = normed
+    if fused:
         out = ops.empty((M, C), ops.act_dtype, xin.device)
         return ops.ff_fused(xin, ff.w1_fused, ff.b1_fused, ff.w2_fused, ff.b2, out, **kw)
     f = ops.linear(xin, ff.w1, ff.b1, geglu=True)

@@ -50,6 +50,8 @@ SIGNATURES = {
     "v3d_sizeof_gemm_args": (c_i32, []),
     "v3d_ff_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32, c_f32,
                              c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "v3d_ln_ff_fused": (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32, c_f32,
+                                c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "v3d_ln_proj": (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp]),
     "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i64,
@@ -416,6 +418,20 @@ class HipOps(OpsBase):
                                           res2.stride(0) if res2 is not None else 0, _ptr(coef), int(coef_rpg), float(c_acc),
                                           float(c_res1), float(c_res2), out.data_ptr(), out.stride(0), M, Cc, hidden, self._stream()),
                     "v3d_ff_fused")
+        return out
+
+    def ln_ff_fused(self, x, eps, w1p, b1, w2p, b2, out, *, res1=None, res2=None, coef=None, coef_rpg=0, c_acc=1.0, c_res1=1.0, c_res2=1.0):
+        """LayerNorm (affine folded into w1p / b1 at pack time) + the fused feed-forward on the un-normalised rows x."""
+        bf = torch.bfloat16
+        for t, nm in ((x, "x"), (w1p, "w1"), (w2p, "w2"), (out, "out")):
+            self._req(t, bf, f"ln_ff.{nm}")
+        M, Cc = x.shape
+        hidden = w2p.shape[-1]
+        self._check(self.lib.v3d_ln_ff_fused(x.data_ptr(), x.stride(0), float(eps), w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                             _ptr(res1), res1.stride(0) if res1 is not None else 0, _ptr(res2),
+                                             res2.stride(0) if res2 is not None else 0, _ptr(coef), int(coef_rpg), float(c_acc),
+                                             float(c_res1), float(c_res2), out.data_ptr(), out.stride(0), M, Cc, hidden, self._stream()),
+                    "v3d_ln_ff_fused")
         return out
 
     LN_PROJ_WIDTHS = (320,)
