@@ -191,6 +191,8 @@ class _Timed:
             self._wrap("ln_proj", m_lnp)
         if hasattr(self.ops, "ff_fused"):
             self._wrap("ff_fused", m_ff)
+        if hasattr(self.ops, "ln_ff_fused"):          # the same kernel with the LayerNorm on its resident rows
+            self._wrap("ln_ff_fused", lambda x, eps, w1p, b1, w2p, b2, out, **kw: m_ff(x, w1p, b1, w2p, b2, out, **kw))
         self._wrap("attn_spatial", m_attn)
         self._wrap("attn_temporal", m_tattn)
         self._wrap("groupnorm_stats", m_gns)
