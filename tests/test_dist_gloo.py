@@ -98,3 +98,65 @@ def test_two_rank_uneven_frame_shard_matches_unsharded():
         assert e_dec <= 5e-5, f"rank {rank}: sharded VAE decode differs from the unsharded reference fixture: {e_dec}"
         assert e_samp <= 5e-5, f"rank {rank}: sharded sampler loop / decode differs from the unsharded result: {e_samp}"
         assert sent > 0
+
+
+def _worker8(rank, world, port, q, T):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    torch.set_grad_enabled(False)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.ops_emul import EmulOps
+        from tiny import build_denoiser, build_sampler
+        from v3d_amd.dist import FrameShard, sharded_sample, sharded_unet_eval
+        from v3d_amd.ops import use_backend
+        from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+        p = TINY
+        sh = FrameShard(T)
+        noise, c, uc, x8, ts, ctx, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+        ioi = torch.zeros(2, T)
+        ioi[1, T // 2] = 1.0
+        B = 2
+        with use_backend(EmulOps("cpu", exact=True)):
+            net = build_unet()
+            out_loc = sharded_unet_eval(net, sh, sh.take_frames(x8, B), None, None, sh.take_frames(ts, B), ctx,
+                                        sh.take_frames(y, B), sh.take_frames(ioi.reshape(-1), B))
+            out = sh.gather_frames_out(out_loc.contiguous(), B)
+            sampler, den, wr = build_sampler(T, steps=2), build_denoiser(), OpenAIWrapper(net)
+            zs = sharded_sample(sh, sampler, den, wr, lambda zz: zz, noise.clone(), c, uc, B=1)
+            e_unet = e_samp = 0.0
+            if rank == 0:      # the unsharded result of the same emulated engine, once
+                full = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi)
+                e_unet = ((out - full).abs().max() / full.abs().max()).item()
+                extra = {"image_only_indicator": torch.zeros(2, T), "num_video_frames": T}
+                zf = sampler(lambda i, s_, cc: den(wr, i, s_, cc, **extra), noise.clone(), cond=c, uc=uc)
+                e_samp = ((zs - zf).abs().max() / zf.abs().max()).item()
+        q.put((rank, sh.T_local, e_unet, e_samp, sh.bytes_sent))
+    except Exception as e:
+        import traceback
+        q.put((rank, -1, traceback.format_exc(), str(e), 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_18_frames_is_the_3_3_2_2_2_2_2_2_split_and_matches_unsharded():
+    """BASELINE.json configs[3]: 18 frames over 8 ranks (3,3,2,2,2,2,2,2) - the partition `bench.py --shard frames` and the secondary
+    frame-sharded run of an 8-GPU replica bench use; every interior rank has two halo neighbours, ranks hold 2 or 3 frames."""
+    world, T = 8, 18
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, T)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    for r in res:
+        assert r[1] >= 0, f"rank {r[0]} failed:\n{r[2]}"
+    res.sort()
+    assert [r[1] for r in res] == [3, 3, 2, 2, 2, 2, 2, 2]
+    assert res[0][2] <= 5e-5 and res[0][3] <= 5e-5, f"sharded vs unsharded (U-Net, 2-step sampler): {res[0][2:4]}"
+    assert all(r[4] > 0 for r in res)
