@@ -45,6 +45,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_HBM_GBPS = 8000.0
+RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)      # 312.5: launches below it are HBM-bound (classified per launch)
 F_UNET_TFLOP = 45.677          # algorithmic FLOPs of one denoiser evaluation (reference graph, cfg batch 36)
 F_VAE_TFLOP_PER_FRAME = 3.043
 PMC_PROFILE = "r02_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
@@ -153,7 +154,12 @@ class _Timed:
             by = (g.A.shape[-2] * g.K * 2 + taps * g.N * g.K * 2) * g.batch + g.M * nout * g.out.element_size() * g.batch
             by += sum(g.M * nout * 2 for r in (g.res1, g.res2) if r is not None)
             fam = {0: "gemm_linear_geglu" if g.geglu else ("gemm_batched" if g.batch > 1 else "gemm_linear"), 1: "gemm_conv3x3", 2: "gemm_convt3"}[g.mode]
-            return fam, 2.0 * g.M * g.N * g.K * taps * g.batch, by
+            fl = 2.0 * g.M * g.N * g.K * taps * g.batch
+            if g.gn_in is not None:
+                fam += "_gn"          # GroupNorm + SiLU applied in the operand path (conv.hip): same algorithmic flops / bytes, no apply pass
+            elif fl / by < RIDGE_FLOP_PER_BYTE:
+                fam += "_hbm"         # classified PER LAUNCH: below the ridge the launch is HBM-bound (the K = 320 / 640 linears at 64x64 / 32x32)
+            return fam, fl, by
 
         def m_ff(x, w1p, b1, w2p, b2, out, **kw):
             # both GEMMs of the block in one launch: 2 M C (2 hidden) + 2 M hidden C flops; bytes = x, both weight matrices, the output and
@@ -174,9 +180,12 @@ class _Timed:
             C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
             return "gn_stats", 0.0, n_img * S * C * 2
 
-        def m_gna(x1, x2, stats, gamma, beta, out, n_img, S, *a):
+        def m_gna(x1, x2, table, out, n_img, S, *a):
             C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
             return "gn_apply", 0.0, 2 * n_img * S * C * 2
+
+        def m_gnf(stats, sums, gamma, beta, count, eps, table):
+            return "gn_finalize", 0.0, (0 if stats is None else stats.numel() * 4) + (0 if table is None else table.numel() * 4)
 
         def m_ln(x, gamma, beta, out, eps, add=None, add_rpg=0, add_ld=0, xsum_out=None):
             return "layernorm", 0.0, (3 if xsum_out is not None else 2) * x.numel() * 2
@@ -197,6 +206,7 @@ class _Timed:
         self._wrap("attn_temporal", m_tattn)
         self._wrap("groupnorm_stats", m_gns)
         self._wrap("groupnorm_apply", m_gna)
+        self._wrap("groupnorm_finalize", m_gnf)
         self._wrap("layernorm", m_ln)
         if hasattr(self.ops, "attn_spatial_fp8"):     # scene-config variant (V3D_ATTN_FP8=1): attention + its two quantisation passes
             self._wrap("attn_spatial_fp8", lambda qk8, sc, v8, vs, out, n_img, S, heads, scale: ("attn_spatial_fp8", 4.0 * n_img * heads * S * S * 64, 3 * n_img * S * heads * 64 + n_img * S * heads * 128))
@@ -230,7 +240,7 @@ def measure_rooflines(step):
         fam = t.families()
     per = []
     for f, (ms, fl, by, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
-        mfma = fl / max(by, 1) > PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9) and fl > 0     # above the ridge -> MFMA-bound
+        mfma = fl / max(by, 1) > RIDGE_FLOP_PER_BYTE and fl > 0 and not f.endswith("_hbm")       # above the ridge -> MFMA-bound
         if f.startswith("attn_spatial") or f.startswith("attn_vae"):
             mfma = True                                                                        # (QK^T / PV re-read K,V from L2, never HBM-bound)
         ach = fl / (ms * 1e-3) / 1e12 if mfma else by / (ms * 1e-3) / 1e9

@@ -24,8 +24,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 3
-#define V3D_GN_SLOTS 32
+#define V3D_ABI_VERSION 4
 
 typedef void* v3d_stream_t; /* hipStream_t */
 
@@ -94,18 +93,36 @@ typedef struct v3d_gemm_args {
                                                  F.pad(x,(0,1,0,1)) + padding=0: the VAE encoder's Downsample (diffusionmodules/model.py:74-91) */
     int64_t sA, sW, sO;                       /* element strides between batches (A, W, out) */
     int64_t halo_rows;                        /* CONVT3 (ABI 3): 0 = dense frames; B*S = split-halo layout, see above */
-    /* (ABI 3) GroupNorm statistics of the OUTPUT, accumulated by the epilogue so that the next GroupNorm needs no statistics pass:
-     * gn_stats[(m / gn_rps)][slot][n / gn_cpg][2] += (sum, sumsq) of the bf16-rounded out[m][n]  (layout of v3d_groupnorm_stats,
-     * V3D_GN_SLOTS slots, caller zeroes).  NULL = off.  Needs a dense bf16 out (ldo == N), !geglu, batch 1, 32 groups of an even number of channels (N == 32 * gn_cpg), gn_rps % 16 == 0,
-     * M % gn_rps == 0.  The persistent big-tile kernels gather the sums in their epilogue; every other launch runs v3d_groupnorm_stats on the
-     * output before returning (same result). */
+    /* GroupNorm statistics of the OUTPUT, gathered by the epilogue so that the next GroupNorm needs no statistics pass (ABI 3; slots ABI 4):
+     * gn_stats[(m / gn_rps)][slot][n / gn_cpg][2] = (sum, sumsq) over the bf16-rounded out[m][n] of ONE writer's rows (layout of
+     * v3d_groupnorm_stats: gn_nslots slots per statistics group, caller zeroes, every slot is written at most once with plain stores - no
+     * atomics, the sums are bit-reproducible).  NULL = off.  Needs a dense bf16 out (ldo == N), !geglu, batch 1, 32 groups of an even
+     * number of channels (N == 32 * gn_cpg), gn_rps % 16 == 0, M % gn_rps == 0, gn_nslots >= gn_rps / 64 + 2.  The persistent big-tile
+     * kernels store the sums from their epilogue; every other launch runs v3d_groupnorm_stats on the output before returning. */
     float* gn_stats;
     int64_t gn_rps;                           /* rows per statistics group (imgs_per_stat * S) */
     int32_t gn_cpg;                           /* channels per group */
-    int32_t reserved0;
+    int32_t gn_in_silu;                       /* (ABI 4) see gn_in_table */
+    int64_t gn_nslots;                        /* (ABI 4) slots per statistics group of gn_stats */
+    /* (ABI 4) GroupNorm (+SiLU) of the INPUT applied in the operand path: the "GN -> SiLU -> conv" of every ResBlock half
+     * (openaimodel.py:267-271,302-314; video_model.py:42-55) and the "GN -> proj_in" of the transformer (attention.py:130-133,692-704)
+     * without the normalised tensor ever existing in memory.  With gn_in_table != NULL, A holds the RAW tensor and the contraction runs on
+     *     a(row, k) = act(A[row][k] * table[row / gn_in_rps][k][0] + table[row / gn_in_rps][k][1]),  act = SiLU when gn_in_silu, rounded to
+     * bf16 (the value v3d_groupnorm_apply would have stored); zero padding stays zero.  table = v3d_groupnorm_finalize's (scale, shift)
+     * table [n_stat][K][2] fp32, gn_in_rows = its n_stat.  A2 != NULL: the input is the channel concatenation A[:, :K1] | A2[:, :K - K1]
+     * (th.cat([h, hs.pop()], 1) of the U-Net's up path, video_model.py:483, never materialised), row stride lda2, same row count.
+     * Only the LDS-haloed kernels implement this (v3d_gemm_gn_in_supported says whether a call is one of their shapes); any other call
+     * with gn_in_table set is refused with V3D_ERR_ARG - normalise with v3d_groupnorm_apply first. */
+    const float* gn_in_table;
+    int64_t gn_in_rps;                        /* source rows per table row (S for a 2-D norm, T*S for the 3-D norm) */
+    int64_t gn_in_rows;                       /* rows (statistics groups) of the table */
+    const void* A2;
+    int64_t K1, lda2;
 } v3d_gemm_args;
 
 int v3d_gemm(const v3d_gemm_args* args, v3d_stream_t stream);
+/* 1 when v3d_gemm would run `args` (with its gn_in_table / A2 fields) on a kernel that normalises the operand in flight, else 0 */
+int v3d_gemm_gn_in_supported(const v3d_gemm_args* args);
 
 /* FeedForward(GEGLU) of the transformer blocks, fused end to end (sgm/modules/attention.py:82-113: GEGLU = Linear(C, 2*hidden) ->
  * value * gelu(gate); FeedForward = GEGLU, Dropout(0), Linear(hidden, C)); the hidden tensor never leaves the CU.
@@ -141,30 +158,38 @@ int v3d_ln_ff_fused(const void* x, int64_t ldx, float ln_eps, const void* W1p, c
  *   outT[m / S][n - n_rm][m % S] = sum_k xh[m][k] W'[n][k] + bias[n]     for n >= n_rm   (V^T layout of v3d_attn_spatial: keys contiguous)
  * Wp = the concatenated [N][C] weight (q ; k ; v, gamma folded in) stored in the kernel's LDS-DMA order (ff_dma_tile_index(N, C, 64, C): slabs of
  * 64 rows, 1-KiB pieces of 16 rows x 32 columns ordered (column block, row block), 16-byte unit 4 r + p of a piece = columns 8 (p ^ swz(r)) .. of
- * row r, swz(r) = {0,2,3,1}[(r >> 2) & 3]).  M % 128 == 0, N % 64 == 0 (<= 1024), n_rm % 64 == 0; S % 128 == 0 when n_rm < N. */
+ * row r, swz(r) = {0,2,3,1}[(r >> 2) & 3]).  M % 128 == 0, N % 64 == 0 (128 <= N <= 960), n_rm % 64 == 0; S % 128 == 0 when n_rm < N. */
 int v3d_ln_proj(const void* x, int64_t ldx, float eps, const void* Wp, const float* bias, void* out, int64_t ldo, void* outT,
                 int64_t M, int32_t C, int32_t N, int32_t n_rm, int64_t S, v3d_stream_t stream);
 /* sizeof(v3d_gemm_args) as compiled into the library: lets a foreign-language binding verify its struct mirror */
 int v3d_sizeof_gemm_args(void);
 
 /* ------------------------------------------------------------------------------------------------
- * GroupNorm (32 groups) over channels-last activations, optionally over two channel-concatenated sources
- * (the U-Net skip concat th.cat([h, hs.pop()], 1) at video_model.py:483 is never materialised).
- *   stats[g_img][slot][group][2] += (sum, sumsq) over rows of the images in that stat group  (fp32 atomics; caller
- *   zeroes; V3D_GN_SLOTS partial-sum slots per group spread the atomics, consumers add the slots up)
- *   imgs_per_stat = 1 for 2-D GroupNorm, = frames-per-sample for the 3-D GroupNorm whose statistics span
- *   all frames (openaimodel.py:267-271,302-305 with dims=3).  Under frame sharding the caller all-reduces `stats`.
- *   apply: y = (x - mean) * rstd * gamma + beta, mean/var from stats and `count` (elements per group, global),
- *   then SiLU when silu != 0; bf16 out [n_img*S][C1+C2].
+ * GroupNorm over channels-last activations, optionally over two channel-concatenated sources (the U-Net skip concat
+ * th.cat([h, hs.pop()], 1) at video_model.py:483 is never materialised), in three steps (ABI 4):
+ *   v3d_groupnorm_stats:    stats[g_img][slot][group][2] = (sum, sumsq) over the rows one block read: every block owns ONE slot
+ *                           (slot = (img % imgs_per_stat) * blocks_per_image + block) and writes it with a plain store - no atomics, the
+ *                           result does not depend on scheduling.  Caller zeroes `stats` [n_img / imgs_per_stat][nslots][groups][2];
+ *                           nslots >= imgs_per_stat (more slots = more blocks; the library fits its grid to nslots).
+ *                           imgs_per_stat = 1 for the 2-D GroupNorm, = frames per sample for the 3-D GroupNorm whose statistics span all
+ *                           frames (openaimodel.py:267-271,302-305 with dims=3).  v3d_gemm's gn_stats epilogue fills the same layout.
+ *   v3d_groupnorm_finalize: adds the slots up in a fixed order in fp64, mean / rstd in fp64, and writes the affine the normalisation
+ *                           amounts to per (statistics group, channel):  table[stat][c] = (gamma[c] rstd, beta[c] - mean gamma[c] rstd),
+ *                           y = x * table[..][0] + table[..][1].  `count` = elements per group (global under frame sharding).
+ *                           `sums` [n_stat][groups][2] fp64 is the hand-off of the frame-sharded runtime: stats != NULL writes it (when
+ *                           given), stats == NULL reads it (after the all-reduce over ranks); table == NULL skips the table.
+ *   v3d_groupnorm_apply:    y = x * scale + shift, then SiLU when silu != 0; bf16 out [n_img*S][C1+C2].  Consumers that normalise their
+ *                           operand in flight (v3d_gemm gn_in_table) take the table instead.
  * replaces GroupNorm32 / Normalize (+SiLU / swish): diffusionmodules/util.py:259-276; attention.py:130-133;
  *   model.py:52-55,43-45; openaimodel.py:267-271,302-305.
  * ---------------------------------------------------------------------------------------------- */
-int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats,
+int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots,
                         int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, v3d_stream_t stream);
-int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* stats,
-                        const float* gamma, const float* beta, void* out, int64_t n_img, int64_t S,
-                        int32_t groups, int64_t imgs_per_stat, double count, float eps, int32_t silu,
-                        v3d_stream_t stream);
+int v3d_groupnorm_finalize(const float* stats, int64_t nslots, double* sums, int64_t n_stat, int32_t groups,
+                           const float* gamma, const float* beta, int64_t C, double count, float eps, float* table,
+                           v3d_stream_t stream);
+int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* table, void* out,
+                        int64_t n_img, int64_t S, int64_t imgs_per_stat, int32_t silu, v3d_stream_t stream);
 
 /* LayerNorm over the last dim of bf16 [M][C]; optional fp32 row-group vector added first:
  *   xs = x + add[(m / add_rpg) * add_ld + c];  if xsum_out: xsum_out[m] = bf16(xs);  out = LN(xs)*gamma + beta

@@ -69,7 +69,30 @@ class EmulOps(OpsBase):
             return acc
         raise ValueError(g.mode)
 
+    def gemm_gn_in_supported(self, g: GemmCall) -> bool:
+        return g.gn_in is not None and g.batch == 1 and not g.geglu      # the emulator normalises any operand
+
+    def _gn_in_operand(self, g: GemmCall):
+        """The operand the contraction sees when GemmCall.gn_in is set: act(x * scale + shift) of the raw rows (A | A2), rounded to the storage dtype."""
+        x = g.A[:, :g.A.shape[-1]].float()
+        if g.A2 is not None:
+            x = torch.cat([x, g.A2.float()], dim=-1)
+        r = torch.arange(x.shape[0], device=x.device)
+        rows = (r - g.a_row0) // g.gn_in_rps
+        if g.mode == GEMM_CONVT3 and g.halo_rows:
+            # split-halo layout (frame sharding): the slabs in front of / behind the local frames hold frame -1 / T of sample 0 .. B-1
+            rows = torch.where(r < g.a_row0, (r - (g.a_row0 - g.halo_rows)) // g.S, rows)
+            rows = torch.where(r >= g.a_row0 + g.M, (r - (g.a_row0 + g.M)) // g.S, rows)
+        rows = rows.clamp(0, g.gn_in.shape[0] - 1)           # (in-line halo frames of a single sample belong to its one statistics group)
+        y = x * g.gn_in[rows, :, 0] + g.gn_in[rows, :, 1]
+        if g.gn_in_silu:
+            y = y * torch.sigmoid(y)
+        return y.to(self.act_dtype)
+
     def gemm(self, g: GemmCall):
+        if g.gn_in is not None:
+            import dataclasses
+            g = dataclasses.replace(g, A=self._gn_in_operand(g), A2=None, gn_in=None)
         for z in range(g.batch):
             A = g.A[z] if (g.A.dim() == 3 and g.mode == GEMM_LINEAR and (g.batch > 1 or g.out.dim() == 3)) else g.A
             W = g.W[z] if (g.W.dim() == 3 and g.mode == GEMM_LINEAR and (g.batch > 1 or g.out.dim() == 3)) else g.W
@@ -114,16 +137,29 @@ class EmulOps(OpsBase):
         stats[:, 0, :, 0] += xg.sum(dim=(1, 3))          # [stat group][slot][group][2]; the emulator uses slot 0 only
         stats[:, 0, :, 1] += (xg * xg).sum(dim=(1, 3))
 
-    def groupnorm_apply(self, x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu):
-        x = self._cat(x1, x2).float()
-        C = x.shape[-1]
-        tot = stats.sum(dim=1)
+    def groupnorm_finalize(self, stats, sums, gamma, beta, count, eps, table):
+        if stats is not None:
+            tot = stats.double().sum(dim=1)              # [n_stat, groups, 2]
+            if sums is not None:
+                sums.copy_(tot)
+        else:
+            tot = sums.double()
+        if table is None:
+            return
+        groups = tot.shape[1]
+        C = gamma.numel()
         mean = tot[..., 0] / count
         var = (tot[..., 1] / count - mean * mean).clamp_min(0)
-        rstd = torch.rsqrt(var + eps)
-        xg = x.reshape(n_img // imgs_per_stat, imgs_per_stat * S, groups, C // groups)
-        y = (xg - mean[:, None, :, None]) * rstd[:, None, :, None]
-        y = y.reshape(n_img * S, C) * gamma.float()[None, :] + beta.float()[None, :]
+        rstd = 1.0 / torch.sqrt(var + eps)
+        sc = gamma.double()[None, :] * rstd.repeat_interleave(C // groups, dim=1)
+        sh = beta.double()[None, :] - mean.repeat_interleave(C // groups, dim=1) * sc
+        table.copy_(torch.stack([sc, sh], dim=-1).float())
+
+    def groupnorm_apply(self, x1, x2, table, out, n_img, S, imgs_per_stat, silu):
+        x = self._cat(x1, x2).float()
+        C = x.shape[-1]
+        xg = x.reshape(n_img // imgs_per_stat, imgs_per_stat * S, C)
+        y = (xg * table[:, None, :, 0] + table[:, None, :, 1]).reshape(n_img * S, C)
         if silu:
             y = y * torch.sigmoid(y)
         out.copy_(y.to(out.dtype))

@@ -36,7 +36,8 @@ def compare(a: torch.Tensor, b: torch.Tensor):
 def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=True, add=False, res=0, coef=False,
               out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0, gn_rps=0):
     """gn_rps > 0: the launch also gathers the GroupNorm partial sums of its output (GemmCall.gn_stats, 32 groups, gn_rps rows per statistics
-    group); they are checked against sums over the rows the kernel itself stored (fp32 atomics: order-dependent, 2e-4 of the largest sum)."""
+    group); they are checked against sums over the rows the kernel itself stored (fp32 partials, one slot per writer: 2e-4 of the largest sum)
+    and a second launch must reproduce output AND statistics bit for bit (no atomics anywhere)."""
     g = torch.Generator().manual_seed(seed)
     kw = {}
     n_out = N // 2 if geglu else N
@@ -82,10 +83,13 @@ def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=Tru
         kw.update(coef=_rand(g, ((M + rpg - 1) // rpg, 3), F32, 1.0, dev), coef_rpg=rpg)
     base = dict(A=A, W=W, M=M, N=N, K=K, mode=mode, geglu=geglu, batch=batch, **kw)
     if gn_rps:
-        from v3d_amd.ops import GN_SLOTS
-        st_h = torch.zeros((M // gn_rps, GN_SLOTS, 32, 2), dtype=F32, device=dev)
+        from v3d_amd.ops import OpsBase
+        st_h = torch.zeros((M // gn_rps, OpsBase.gn_nslots(gn_rps), 32, 2), dtype=F32, device=dev)
         st_e = torch.zeros_like(st_h)
+        st_2, out_2 = torch.zeros_like(st_h), torch.zeros_like(out_h)
+        hip.gemm(GemmCall(out=out_2, gn_stats=st_2, gn_rps=gn_rps, gn_cpg=N // 32, **base))
         hip.gemm(GemmCall(out=out_h, gn_stats=st_h, gn_rps=gn_rps, gn_cpg=N // 32, **base))
+        assert torch.equal(out_2, out_h) and torch.equal(st_2, st_h), "two identical launches differ: the statistics epilogue is not deterministic"
         emu.gemm(GemmCall(out=out_e, gn_stats=st_e, gn_rps=gn_rps, gn_cpg=N // 32, **base))
         v = out_h.float().reshape(M // gn_rps, gn_rps, 32, N // 32)
         want = torch.stack([v.sum(dim=(1, 3)), (v * v).sum(dim=(1, 3))], dim=-1)
@@ -131,15 +135,28 @@ def case_ff_fused(hip, emu, dev, *, M, C=320, hidden=1280, res=1, coef=False, se
     return compare(o_h, o_e)
 
 
-def case_groupnorm(hip, emu, dev, *, n_img, S, C1, C2=0, imgs_per_stat=1, eps=1e-5, silu=True, seed=0):
+def case_groupnorm(hip, emu, dev, *, n_img, S, C1, C2=0, imgs_per_stat=1, eps=1e-5, silu=True, seed=0, mean=0.5, std=1.0):
+    """GroupNorm (stats -> finalize -> apply) against the emulation, and - independent of it - against torch.nn.functional.group_norm in
+    fp64 on the same bf16 input.  mean / std: per-channel offsets up to `mean` x the spread (real SVD checkpoints have channels with
+    |mean| >> std: E[x^2] - E[x]^2 in fp32 would cancel there; the finalize step works in fp64).  Two identical calls must agree bit for bit."""
     g = torch.Generator().manual_seed(seed)
-    x1 = (_rand(g, (n_img * S, C1), F32, 1.0, dev) + 0.5).to(BF)
-    x2 = (_rand(g, (n_img * S, C2), F32, 2.0, dev) - 0.3).to(BF) if C2 else None
     C = C1 + C2
+    off = (torch.rand((C,), generator=g) * 2 - 1) * mean
+    x1 = (_rand(g, (n_img * S, C1), F32, std, dev) + off[:C1].to(dev)).to(BF)
+    x2 = (_rand(g, (n_img * S, C2), F32, 2.0 * std, dev) - off[C1:].to(dev)).to(BF) if C2 else None
     gamma, beta = _rand(g, (C,), F32, 0.3, dev) + 1.0, _rand(g, (C,), F32, 0.3, dev)
     o_h = hip.groupnorm(x1, x2, gamma, beta, n_img, S, eps=eps, silu=silu, imgs_per_stat=imgs_per_stat)
+    o_2 = hip.groupnorm(x1, x2, gamma, beta, n_img, S, eps=eps, silu=silu, imgs_per_stat=imgs_per_stat)
+    assert torch.equal(o_h, o_2), "two identical GroupNorm calls differ: statistics are not deterministic"
     o_e = emu.groupnorm(x1, x2, gamma, beta, n_img, S, eps=eps, silu=silu, imgs_per_stat=imgs_per_stat)
-    return compare(o_h, o_e)
+    # fp64 reference: [n_stat, C, ips * S] in the layout F.group_norm wants
+    x = (x1 if x2 is None else torch.cat([x1, x2], dim=-1)).double().reshape(n_img // imgs_per_stat, imgs_per_stat * S, C).permute(0, 2, 1)
+    y = torch.nn.functional.group_norm(x, 32, gamma.double(), beta.double(), eps).permute(0, 2, 1).reshape(n_img * S, C)
+    if silu:
+        y = y * torch.sigmoid(y)
+    r64, c64 = compare(o_h, y)
+    rel, cos = compare(o_h, o_e)
+    return max(rel, r64), min(cos, c64)
 
 
 def case_layernorm(hip, emu, dev, *, M, C, add=False, seed=0):
@@ -256,6 +273,69 @@ def case_attn_fp8(hip, emu, dev, *, n_img, S, heads, seed=0, what="attn"):
         emu.attn_spatial_fp8(qk8_h, sc_h, v8_h, vs_h, o_e, n_img, S, heads, 0.125)
     else:
         hip.attn_spatial(qk[:, :C], qk[:, C:], vT, o_e, n_img, S, heads, 0.125)
+    return compare(o_h, o_e)
+
+
+def case_conv_gn(hip, emu, dev, *, N, C1, C2=0, conv=None, convt=None, add=False, res=0, coef=False, gn_out=False, silu=True, seed=0,
+                 expect_fused=True, mean=0.5):
+    """GroupNorm (+SiLU) in the operand path of the convolution (GemmCall.gn_in / A2): the LDS-haloed kernels normalise the raw input
+    tile on its way into LDS.  Reference = the emulation (normalise -> round to bf16 -> convolution); the statistics table comes from the
+    product's own stats / finalize kernels.  conv = (n_img, H, W) 3x3 stride 1; convt = (B, T, S) the (3,1,1) conv with the 3-D norm."""
+    from v3d_amd.ops import OpsBase
+    g = torch.Generator().manual_seed(seed)
+    K = C1 + C2
+    if conv is not None:
+        n_img, H, W = conv
+        S, ips, mode = H * W, 1, GEMM_CONV3X3
+        kw = dict(mode=mode, Hin=H, Win=W, Hout=H, Wout=W)
+        taps = 9
+    else:
+        B, T, S = convt
+        n_img, ips, mode = B * T, T, GEMM_CONVT3
+        kw = dict(mode=mode, T=T, S=S, tmin=0, tmax=T - 1)
+        taps = 3
+    M = n_img * S
+    off = (torch.rand((K,), generator=g) * 2 - 1) * mean
+    x1 = (_rand(g, (M, C1), F32, 1.0, dev) + off[:C1].to(dev)).to(BF)
+    x2 = (_rand(g, (M, C2), F32, 1.5, dev) + off[C1:].to(dev)).to(BF) if C2 else None
+    gamma, beta = _rand(g, (K,), F32, 0.3, dev) + 1.0, _rand(g, (K,), F32, 0.3, dev)
+    table = hip.groupnorm_table(x1, x2, gamma, beta, n_img, S, eps=1e-5, imgs_per_stat=ips)
+    Wt = _rand(g, (taps, N, K), scale=1 / math.sqrt(K * taps), device=dev)
+    kw.update(bias=_rand(g, (N,), F32, 0.5, dev))
+    if add:
+        kw.update(add=_rand(g, (n_img, N + 24), F32, 0.5, dev), add_rpg=S, add_ld=N + 24)
+    if res >= 1:
+        kw.update(res1=_rand(g, (M, N), device=dev), c_res1=0.75, c_acc=0.6)
+    if coef:
+        kw.update(coef=_rand(g, (n_img, 3), F32, 1.0, dev), coef_rpg=S)
+    base = dict(A=x1, A2=x2, W=Wt, M=M, N=N, K=K, gn_in=table, gn_in_rps=ips * S, gn_in_silu=silu, **kw)
+    o_h = torch.zeros((M, N), dtype=BF, device=dev)
+    o_e = torch.zeros_like(o_h)
+    skw_h, skw_e = {}, {}
+    if gn_out:
+        rps = ips * S
+        st_h = torch.zeros((M // rps, OpsBase.gn_nslots(rps, ips), 32, 2), dtype=F32, device=dev)
+        skw_h = dict(gn_stats=st_h, gn_rps=rps, gn_cpg=N // 32)
+        skw_e = dict(gn_stats=torch.zeros_like(st_h), gn_rps=rps, gn_cpg=N // 32)
+    call = GemmCall(out=o_h, **base, **skw_h)
+    fused = hip.gemm_gn_in_supported(call)
+    assert fused == expect_fused, f"gemm_gn_in_supported = {fused}, the case expects {expect_fused}"
+    if not fused:
+        return 0.0, 1.0
+    hip.gemm(call)
+    emu.gemm(GemmCall(out=o_e, **base, **skw_e))
+    o_2 = torch.zeros_like(o_h)
+    if gn_out:
+        st_2 = torch.zeros_like(st_h)
+        hip.gemm(GemmCall(out=o_2, **base, **dict(skw_h, gn_stats=st_2)))
+        assert torch.equal(st_2, st_h), "statistics epilogue of the haloed kernel is not deterministic"
+        v = o_h.float().reshape(M // rps, rps, 32, N // 32)
+        want = torch.stack([v.sum(dim=(1, 3)), (v * v).sum(dim=(1, 3))], dim=-1)
+        err = ((st_h.sum(dim=1) - want).abs().max() / want.abs().max()).item()
+        assert err <= 2e-4, f"gn_stats epilogue of the haloed kernel: partial sums off by {err:.3e} of the largest sum"
+    else:
+        hip.gemm(GemmCall(out=o_2, **base))
+    assert torch.equal(o_2, o_h), "two identical launches of the haloed kernel differ"
     return compare(o_h, o_e)
 
 
@@ -386,6 +466,23 @@ def all_cases(full: bool = True):
         ("gn3d_T3", case_groupnorm, dict(n_img=6, S=64, C1=320, imgs_per_stat=3), TOL_BF16),
         ("gn_vae_128", case_groupnorm, dict(n_img=2, S=1024, C1=128, eps=1e-6), TOL_BF16),
         ("gn_S1", case_groupnorm, dict(n_img=3, S=1, C1=64), TOL_BF16),
+        # channels with |mean| up to 30 / 100 x their spread (fp64 F.group_norm on the same bf16 input is the reference)
+        ("gn2d_offcentre_30", case_groupnorm, dict(n_img=3, S=1024, C1=320, mean=30.0, seed=11), TOL_BF16),
+        ("gn2d_offcentre_100", case_groupnorm, dict(n_img=2, S=1024, C1=640, mean=100.0, seed=12), TOL_BF16),
+        ("gn3d_offcentre_100", case_groupnorm, dict(n_img=6, S=256, C1=320, imgs_per_stat=3, mean=100.0, std=0.5, seed=13), TOL_BF16),
+        # GroupNorm + SiLU in the operand path of the LDS-haloed convolutions (conv.hip)
+        ("conv_gn_64_plain", case_conv_gn, dict(N=320, C1=320, conv=(3, 64, 64)), TOL_BF16),
+        ("conv_gn_64_straddle_add_gnout", case_conv_gn, dict(N=320, C1=64, conv=(5, 64, 64), add=True, gn_out=True, seed=1), TOL_BF16),
+        ("conv_gn_64_concat_res", case_conv_gn, dict(N=320, C1=64, C2=32, conv=(3, 64, 64), res=1, seed=2), TOL_BF16),
+        ("conv_gn_32_n640", case_conv_gn, dict(N=640, C1=96, conv=(6, 32, 32), add=True, gn_out=True, seed=3), TOL_BF16),
+        ("conv_gn_16_n1280", case_conv_gn, dict(N=1280, C1=64, C2=64, conv=(12, 16, 16), res=1, gn_out=True, seed=4), TOL_BF16),
+        ("conv_gn_64_offcentre", case_conv_gn, dict(N=320, C1=64, conv=(3, 64, 64), mean=30.0, seed=5), TOL_BF16),
+        ("conv_gn_nosilu", case_conv_gn, dict(N=320, C1=32, conv=(3, 32, 32), silu=False, seed=6), TOL_BF16),
+        ("conv_gn_unsupported_8x8", case_conv_gn, dict(N=1280, C1=64, conv=(36, 8, 8), expect_fused=False), TOL_BF16),
+        ("convt_gn_T6", case_conv_gn, dict(N=320, C1=64, convt=(2, 6, 1024), res=1, coef=True, seed=7), TOL_BF16),
+        ("convt_gn_T18_add_gnout", case_conv_gn, dict(N=320, C1=96, convt=(2, 18, 256), add=True, gn_out=True, seed=8), TOL_BF16),
+        ("convt_gn_T12_n640", case_conv_gn, dict(N=640, C1=64, convt=(1, 12, 64), res=1, seed=9), TOL_BF16),
+        ("convt_gn_unsupported_T5", case_conv_gn, dict(N=320, C1=64, convt=(2, 5, 64), expect_fused=False), TOL_BF16),
         ("ln_320", case_layernorm, dict(M=257, C=320), TOL_BF16),
         ("ln_1280_add", case_layernorm, dict(M=96, C=1280, add=True), TOL_BF16),
         ("ln_64", case_layernorm, dict(M=33, C=64, add=True), TOL_BF16),
@@ -436,6 +533,12 @@ def all_cases(full: bool = True):
             ("gemm_V3D_qk_L2", case_gemm, dict(M=36 * 256, N=2560, K=1280, bias=False), TOL_BF16),
             ("gemm_V3D_emb_M36", case_gemm, dict(M=36, N=1280, K=1280, out_fp32=True), TOL_BF16),
             ("conv3x3_V3D_L0", case_gemm, dict(M=0, N=320, K=320, mode=C3, conv=(4, 64, 64, 1, 1), add=True), TOL_BF16),
+            ("conv_gn_V3D_L0_in", case_conv_gn, dict(N=320, C1=320, conv=(36, 64, 64), add=True, gn_out=True, seed=21), TOL_BF16),
+            ("conv_gn_V3D_L0_concat960", case_conv_gn, dict(N=320, C1=640, C2=320, conv=(6, 64, 64), add=True, gn_out=True, seed=22), TOL_BF16),
+            ("conv_gn_V3D_L1_out", case_conv_gn, dict(N=640, C1=640, conv=(36, 32, 32), res=1, gn_out=True, seed=23), TOL_BF16),
+            ("conv_gn_V3D_L2_concat2560", case_conv_gn, dict(N=1280, C1=1280, C2=1280, conv=(36, 16, 16), add=True, gn_out=True, seed=24), TOL_BF16),
+            ("convt_gn_V3D_L0", case_conv_gn, dict(N=320, C1=320, convt=(2, 18, 4096), res=1, coef=True, seed=25), TOL_BF16),
+            ("convt_gn_V3D_L1", case_conv_gn, dict(N=640, C1=640, convt=(2, 18, 1024), add=True, gn_out=True, seed=26), TOL_BF16),
             ("conv3x3_V3D_L3_2560", case_gemm, dict(M=0, N=1280, K=2560, mode=C3, conv=(36, 8, 8, 1, 1), res=1), TOL_BF16),
             ("conv3x3_V3D_down", case_gemm, dict(M=0, N=320, K=320, mode=C3, conv=(4, 64, 64, 2, 1)), TOL_BF16),
             ("conv3x3_V3D_up", case_gemm, dict(M=0, N=640, K=640, mode=C3, conv=(4, 32, 32, 1, 2)), TOL_BF16),

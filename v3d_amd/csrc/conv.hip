@@ -1,0 +1,554 @@
+// LDS-haloed convolution with GroupNorm (+SiLU) applied in the operand path (gfx950) - the "GN -> SiLU -> conv" of every ResBlock half.
+//
+// Reference: ResBlock in_layers / out_layers = GroupNorm32 -> SiLU -> conv (sgm/modules/diffusionmodules/openaimodel.py:267-271,302-314),
+// the same with the (3,1,1) Conv3d in the time_stack of VideoResBlock (video_model.py:42-55, temporal_ae.py:32-44).  Rounds 1-2 ran it as
+// v3d_groupnorm_apply (read + write of the activation tensor) followed by an implicit-GEMM convolution whose every tap re-fetched its
+// activation rows L2 -> LDS (9 x per element for the 3x3, 5.8x the algorithmic bytes measured).  Here:
+//   * a tile = 192 consecutive output pixels (whole image rows) x 320 output channels, persistent blocks of 8 waves, accumulators and
+//     epilogue exactly as gemm_kernel_v3<192, 320> (gemm.hip) - bias / emb vector / residual / alpha blend / GroupNorm statistics of the
+//     output all stay fused;
+//   * per 32-channel chunk the tile's HALO - (rows + 2) x (W + 2) pixels for the 3x3, (frames + 2) x 32 positions for the temporal conv -
+//     is fetched ONCE, raw, by LDS-DMA into a double-buffered LDS image (64 B per pixel, lines padded to a multiple of 8 pixels so a tap's
+//     line offset never changes the bank swizzle);
+//   * the wave that fetched a 1-KiB piece normalises it IN PLACE: ds_read 16 B -> x * scale + shift (the per-(image, channel) affine of
+//     v3d_groupnorm_finalize, staged per chunk in a 512-byte wave-private LDS slot) -> SiLU -> bf16 -> ds_write, one instruction of that
+//     chain per MFMA issue slot of the tap steps (fenced, the ff.hip way), so the VALU work hides behind the matrix pipe;
+//   * the nine (three) taps read SHIFTED fragments of the same image - fragment address = per-lane base for the tap's dx + an immediate
+//     for its dy - and only the weights stream per (chunk, tap) step through the 4-deep LDS-DMA ring of the v3 kernel;
+//   * pixels outside the image are out-of-range DMA sources (zeros) normalised with a zero affine (-> 0, what the padding is); (row, dy)
+//     pairs that would cross an image boundary inside the flat pixel order read their fragment from a zero page instead.
+// L2 -> LDS fill per chunk and CU drops from 9 x 12 KiB (activations) + 180 KiB (weights) to 23 + 180 KiB, the GroupNorm apply pass and
+// its 2 x 94 MB of HBM traffic per use disappear.
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace {
+
+enum { HM_CONV = 0, HM_TEMP = 1 };
+
+template <int HM, int W_>
+struct HaloGeom {
+    static constexpr int BM = 192, BN = 320;
+    static constexpr int NT = HM == HM_CONV ? 9 : 3;                                  // taps = steps per 32-channel chunk
+    static constexpr int LINE = HM == HM_CONV ? ((W_ + 2 + 7) / 8) * 8 : 32;          // halo pixels per line (image row / frame)
+    static constexpr int NLINES = HM == HM_CONV ? BM / W_ + 2 : 8;                    // 3x3: tile rows + 2; temporal: 6 frames + 2
+    static constexpr int HROWS = NLINES * LINE;
+    static constexpr int HPW = ((HROWS + 15) / 16 + 7) / 8;                           // 1-KiB halo pieces per wave
+    static constexpr int HBYTES = HPW * 8 * 1024;
+    static constexpr int NBUF = HM == HM_CONV ? 2 : 3;                                // halo images in flight
+    static constexpr int LA = NBUF - 1;                                               // chunks of look-ahead of the halo loader
+    static constexpr int XF0 = 3;                                                     // first step (after the issue step) whose MFMA slots carry the transform
+    static constexpr int XFN = LA * NT - 4;                                           // ... and how many steps do
+    static constexpr int NTAB = XF0 >= NT ? 2 : 1;                                    // (scale, shift) slots per wave: 2 when a chunk's chain runs beside the next issue
+    static_assert(XFN >= 1, "halo pipeline too shallow");
+};
+
+// halo pixel row -> XOR on the 16-byte chunk position.  Fragments start at ARBITRARY pixel rows (tap shifts), so the swizzle must keep
+// ds_read_b128 conflict-free for every start row: its lane groups read rows {r..r+3, r+12..r+15} at chunk c and {r+4..r+11} at c ^ 1; per
+// row residue mod 4 that is four consecutive 4-row blocks q0..q0+3 at chunk bits (0,1,1,0), and f(q) = 2 (q & 1) makes the four 16-byte
+// slots {f(q0), 1^f(q0+1), 1^f(q0+2), f(q0+3)} distinct for either parity of q0 (the gemm.hip swizzle {0,2,3,1} only does for q0 = 0).
+__device__ __forceinline__ int hswz(int hp) { return (hp >> 1) & 2; }
+__device__ __forceinline__ int wswz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // weight rows: as gemm.hip swz_row<1>
+
+// one instruction of the in-place normalisation chain per call; 15 calls handle one channel pair (see the kernel comment)
+struct XfState {
+    u32x4 raw;             // the 16-byte vector being normalised (re-loaded with the next one as soon as its last pair is unpacked)
+    f32x4 tab;             // (scale, shift) x 2 of the current channel pair (re-loaded for the next pair once both fmas have issued)
+    u32x4 out;
+    float x0, x1, y0, y1, t0, t1;
+};
+
+template <int HM, int W_, bool XF, bool GN>
+__global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
+    using G = HaloGeom<HM, W_>;
+    constexpr int BM = G::BM, BN = G::BN, NT = G::NT, LINE = G::LINE, HPW = G::HPW, HBYTES = G::HBYTES, NBUF = G::NBUF;
+    constexpr int NS = 4, NW = 8, ROWB = 64;
+    constexpr int WM = 96, WN = 80, MF = 6, NF = 5;
+    constexpr int WSTAGE = BN * ROWB;                     // 20 KiB of weights per (chunk, tap) step
+    constexpr int EPI_REGION = 16 * (NF * 32 + 16);
+    constexpr int RING_OFF = 0, HALO_OFF = NS * WSTAGE, ZERO_OFF = HALO_OFF + NBUF * HBYTES, TAB_OFF = ZERO_OFF + 1024,
+                  EPI_OFF = TAB_OFF + NW * 512 * G::NTAB;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_OFF + NW * EPI_REGION];   // the ONLY __shared__ object
+    static_assert(sizeof(lds) <= 160 * 1024, "LDS budget");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 2, wn = wave & 3;             // waves 2 (M) x 4 (N): wave tile 96 x 80
+    unsigned char* estage = lds + EPI_OFF + wave * EPI_REGION;
+
+    const int Gd = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + Gd - 1) / Gd;
+    auto tile_origin = [&](int it, int& tm, long long& n0) __attribute__((always_inline)) {
+        const int id = xcd_remap((int)blockIdx.x + it * Gd, ntiles);
+        int tn;
+        tile_coords(p, id, tm, tn);
+        n0 = (long long)tn * BN;
+    };
+    // first source pixel row of tile row-block tm (3x3: flat pixel order; temporal: (sample, frame block, position block))
+    const int nchunks = (int)(p.K / 32);
+    const int k1chunks = (int)(p.K1 / 32);
+    const int H = p.Hout;
+    const int sblocks = HM == HM_TEMP ? (int)(p.S / 32) : 1;      // temporal: position blocks per frame
+    const int tblocks = HM == HM_TEMP ? p.T / 6 : 1;
+
+    // ---------------------------------------------------------------- weight loader (3 steps ahead of the consumer)
+    const bufrsrc_t rsW = make_rsrc(p.W, p.w_bytes);
+    const int prow = lane >> 2;
+    const unsigned kchunk_w = (unsigned)(((lane & 3) ^ wswz(prow)) * 16);
+    unsigned voffW[3];
+    int w_it = 0, w_c = 0;                                // weight cursor: tile, chunk (its tap is static in the unrolled step bodies)
+    const unsigned tap_bytes = (unsigned)(p.N * p.ldw * 2);
+    auto set_wtile = [&](int it) __attribute__((always_inline)) {
+        int tm;
+        long long n0 = 0;
+        if (it < my_tiles) tile_origin(it, tm, n0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const long long n = n0 + (wave + NW * i) * 16 + prow;
+            voffW[i] = (it < my_tiles && n < p.N) ? (unsigned)(n * p.ldw * 2) + kchunk_w : kInvalid;
+        }
+    };
+    auto issue_w = [&](int stage, int ltap) __attribute__((always_inline)) {
+        const int so = (int)(ltap * tap_bytes) + w_c * 64;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < 2 || grp == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + RING_OFF + stage * WSTAGE + (wave + NW * i) * 1024), 16,
+                                                         (int)voffW[i], so, 0, 0);
+    };
+    // ---------------------------------------------------------------- halo loader (LA chunks ahead)
+    const bufrsrc_t rsA1 = make_rsrc(p.A, p.a_bytes);
+    const bufrsrc_t rsA2 = make_rsrc(p.A2 ? p.A2 : p.A, p.A2 ? p.a2_bytes : p.a_bytes);
+    const bufrsrc_t rsT = make_rsrc(p.gn_in ? (const void*)p.gn_in : (const void*)p.A, p.gn_in ? p.gn_in_bytes : 0u);
+    int h_it = 0, h_c = 0, h_buf = 0;                    // halo cursor: tile, chunk, LDS image it writes
+    unsigned hsrow[HPW];                                  // source pixel row of this lane's halo pixel of piece i (kInvalid: padding)
+    unsigned htab[HPW];                                   // LDS byte address of its (scale, shift) pairs: table slot (+256: second statistics group) or the zero page
+    unsigned hstatA = 0, hstatB = 0;
+    int h_tab = 0;                                        // table slot the next issue fills
+    unsigned latch_base = 0, latch_tab[HPW];              // image / table addresses of the last issue, picked up by its normalisation chain
+    // piece i of this wave = halo pixel rows (wave + 8 i) * 16 .. + 15; the lane holds 16 bytes of pixel row + (lane >> 2).  Pieces start at
+    // multiples of 16 rows, so the swizzle (bit 2 of the pixel row) - and with it the logical 16-byte chunk (8 channels) the lane holds - is
+    // the same for every piece
+    const int hchunkpos = (lane & 3) ^ hswz(lane >> 2);
+    const unsigned hvec0 = (unsigned)(wave * 1024 + lane * 16);      // LDS byte offset of the lane's vector of piece 0 inside a halo image
+    const unsigned tabslot0 = (unsigned)(TAB_OFF + wave * 512 * G::NTAB);
+    auto set_htile = [&](int it) __attribute__((always_inline)) {
+        int tm = 0;
+        long long n0;
+        const bool live = it < my_tiles;
+        if (live) tile_origin(it, tm, n0);
+        long long rowA = -1, rowB = -1;                   // first / last valid source row of the halo (wave-uniform by construction below)
+        if (HM == HM_CONV) {
+            const long long fr0 = (long long)tm * (BM / W_);                  // first flat image row of the tile
+            const long long nfr = p.M / W_;
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                const int hp = (wave + NW * i) * 16 + (lane >> 2);
+                const int line = hp / LINE, x = hp - line * LINE - 1;
+                const long long fr = fr0 - 1 + line;
+                const bool ok = live && x >= 0 && x < W_ && fr >= 0 && fr < nfr && line < G::NLINES;
+                hsrow[i] = ok ? (unsigned)(fr * W_ + x) : kInvalid;
+            }
+            const long long f_lo = fr0 - 1 < 0 ? 0 : fr0 - 1, f_hi = fr0 + BM / W_ >= nfr ? nfr - 1 : fr0 + BM / W_;
+            rowA = f_lo * W_;
+            rowB = f_hi * W_;
+        } else {
+            // tile row-block tm = (sample b, frame block tb, position block sb), positions fastest
+            const int sb = tm % sblocks, tb = (tm / sblocks) % tblocks, b = tm / (sblocks * tblocks);
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                const int hp = (wave + NW * i) * 16 + (lane >> 2);
+                const int line = hp >> 5, s = hp & 31;
+                const int fr = tb * 6 - 1 + line;                              // frame of the sample
+                const bool ok = live && fr >= p.tmin && fr <= p.tmax;
+                long long row = ((long long)b * p.T + fr) * p.S + sb * 32 + s;
+                if (p.halo_rows > 0) {                                         // frame sharding: frame -1 / T live in the slabs around the local frames
+                    if (fr < 0) row = (long long)b * p.S + sb * 32 + s - p.halo_rows;
+                    else if (fr >= p.T) row = p.M + (long long)b * p.S + sb * 32 + s;
+                }
+                hsrow[i] = ok ? (unsigned)(row + p.a_row0) : kInvalid;
+            }
+            rowA = rowB = (long long)b * p.T * p.S;                            // one statistics group per sample (the 3-D GroupNorm)
+        }
+        hstatA = (unsigned)__builtin_amdgcn_readfirstlane((int)(rowA / (p.gn_in_rps > 0 ? p.gn_in_rps : 1)));
+        hstatB = (unsigned)__builtin_amdgcn_readfirstlane((int)(rowB / (p.gn_in_rps > 0 ? p.gn_in_rps : 1)));
+        if (XF) {
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                unsigned st = hstatA;
+                if (HM == HM_CONV && hsrow[i] != kInvalid) st = (unsigned)((long long)hsrow[i] / p.gn_in_rps);
+                htab[i] = hsrow[i] == kInvalid ? (unsigned)ZERO_OFF + (unsigned)hchunkpos * 64u
+                                               : tabslot0 + (st != hstatA ? 256u : 0u) + (unsigned)hchunkpos * 64u;
+            }
+        }
+    };
+    auto issue_halo = [&]() __attribute__((always_inline)) {
+        if (h_c == 0) set_htile(h_it);
+        const bool second = h_c >= k1chunks;
+        const int cc = second ? h_c - k1chunks : h_c;
+        const unsigned ld2 = (unsigned)((second ? p.lda2 : p.lda) * 2);
+        if (XF && lane < 32) {
+            // (scale, shift) of this chunk's 32 channels for the (at most two) statistics groups of the halo: 2 x 256 B
+            const unsigned st = lane < 16 ? hstatA : hstatB;
+            const unsigned vo = (unsigned)(((long long)st * p.K + (long long)h_c * 32) * 8) + (unsigned)(lane & 15) * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (__attribute__((address_space(3))) void*)(lds + TAB_OFF + (wave * G::NTAB + h_tab) * 512), 16, (int)(h_it < my_tiles ? vo : kInvalid), 0, 0, 0);
+        }
+        latch_base = (unsigned)(HALO_OFF + h_buf * HBYTES);
+        if (G::NTAB == 2) {
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) latch_tab[i] = htab[i] + (htab[i] >= (unsigned)TAB_OFF ? (unsigned)(h_tab * 512) : 0u);
+            h_tab ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < HPW; ++i) {
+            const unsigned vo = hsrow[i] == kInvalid ? kInvalid : hsrow[i] * ld2 + (unsigned)hchunkpos * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rsA2 : rsA1, (__attribute__((address_space(3))) void*)(lds + HALO_OFF + h_buf * HBYTES + (wave + NW * i) * 1024), 16,
+                                                     (int)vo, cc * 64, 0, 0);
+        }
+        if (++h_c == nchunks) {
+            h_c = 0;
+            ++h_it;
+        }
+        h_buf = h_buf + 1 == NBUF ? 0 : h_buf + 1;
+    };
+    // ---------------------------------------------------------------- the in-place normalisation of the image the loader filled last
+    // image being normalised: the one issue_halo wrote at the last issue step
+    unsigned xf_base = 0, xf_tab[HPW];                    // LDS byte address of that image / of each vector's (scale, shift) pairs
+    XfState xs;
+    auto xf_read_vec = [&](int v) __attribute__((always_inline)) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(lds + xf_base + hvec0 + v * 8192);
+    };
+    auto xf_read_tab = [&](int v, int e) __attribute__((always_inline)) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(lds + (G::NTAB == 2 ? xf_tab[v] : htab[v]) + e * 16);
+    };
+    // OP = 15 * (4 * vector + pair) + stage.  Every result is pinned to its slot by an empty volatile asm: the steps are several basic blocks (the
+    // two wave groups pass the barrier at different points) and without the pins MachineSink moves the whole chain down to the block of its
+    // only consumer, the ds_write - en bloc in front of the next step's MFMAs.
+    auto xf_op = [&](auto op_) __attribute__((always_inline)) {
+        constexpr int OP = decltype(op_)::value;
+        constexpr int NOPS = HPW * 4 * 15;
+        if constexpr (XF && OP >= 0 && OP < NOPS) {
+            constexpr int pr = OP / 15, st = OP % 15, v = pr / 4, e = pr % 4;
+            const bool silu_on = p.gn_in_silu != 0;
+            if constexpr (st == 0) {
+                xs.x0 = bflo(xs.raw[e]); asm volatile("" : "+v"(xs.x0));
+            } else if constexpr (st == 1) {
+                xs.x1 = bfhi(xs.raw[e]); asm volatile("" : "+v"(xs.x1));
+                if constexpr (e == 3 && v + 1 < HPW) xs.raw = xf_read_vec(v + 1);     // 14 slots ahead of its first use
+            } else if constexpr (st == 2) {
+                xs.y0 = __builtin_fmaf(xs.x0, xs.tab[0], xs.tab[1]); asm volatile("" : "+v"(xs.y0));
+            } else if constexpr (st == 3) {
+                xs.y1 = __builtin_fmaf(xs.x1, xs.tab[2], xs.tab[3]); asm volatile("" : "+v"(xs.y1));
+                if constexpr (pr + 1 < HPW * 4) xs.tab = xf_read_tab((pr + 1) / 4, (pr + 1) % 4);   // 14 slots ahead of its first use
+            } else if constexpr (st == 4) {
+                xs.t0 = xs.y0 * -1.4426950408889634f; asm volatile("" : "+v"(xs.t0));
+            } else if constexpr (st == 5) {
+                xs.t1 = xs.y1 * -1.4426950408889634f; asm volatile("" : "+v"(xs.t1));
+            } else if constexpr (st == 6) {
+                xs.t0 = __builtin_amdgcn_exp2f(xs.t0); asm volatile("" : "+v"(xs.t0));
+            } else if constexpr (st == 7) {
+                xs.t1 = __builtin_amdgcn_exp2f(xs.t1); asm volatile("" : "+v"(xs.t1));
+            } else if constexpr (st == 8) {
+                xs.t0 = 1.0f + xs.t0; asm volatile("" : "+v"(xs.t0));
+            } else if constexpr (st == 9) {
+                xs.t1 = 1.0f + xs.t1; asm volatile("" : "+v"(xs.t1));
+            } else if constexpr (st == 10) {
+                xs.t0 = __builtin_amdgcn_rcpf(xs.t0); asm volatile("" : "+v"(xs.t0));
+            } else if constexpr (st == 11) {
+                xs.t1 = __builtin_amdgcn_rcpf(xs.t1); asm volatile("" : "+v"(xs.t1));
+            } else if constexpr (st == 12) {
+                xs.y0 = silu_on ? xs.y0 * xs.t0 : xs.y0; asm volatile("" : "+v"(xs.y0));
+            } else if constexpr (st == 13) {
+                xs.y1 = silu_on ? xs.y1 * xs.t1 : xs.y1; asm volatile("" : "+v"(xs.y1));
+            } else {
+                { unsigned pk = pack2bf(xs.y0, xs.y1); asm volatile("" : "+v"(pk)); xs.out[e] = pk; }
+                if constexpr (e == 3) {
+                    const unsigned wa = lds_addr(lds) + xf_base + hvec0 + v * 8192;
+                    const u32x4 wv = xs.out;
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(wa), "v"(wv) : "memory");
+                }
+            }
+        }
+    };
+    auto xf_begin = [&]() __attribute__((always_inline)) {          // first reads of an image (its DMA pieces have landed: counted waits below)
+        if (XF) {
+            xf_base = latch_base;
+            if (G::NTAB == 2) {
+#pragma unroll
+                for (int i = 0; i < HPW; ++i) xf_tab[i] = latch_tab[i];
+            }
+            xs.raw = xf_read_vec(0);
+            xs.tab = xf_read_tab(0, 0);
+        }
+    };
+
+    // ---------------------------------------------------------------- consumer state
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[MF], wf[NF];
+    const int wfrag_off = (lane & 15) * ROWB + (((lane >> 4) ^ wswz(lane & 15)) * 16) + wn * WN * ROWB;
+    // activation fragment i of the wave = tile rows wm * 96 + i * 16 .. + 15 = 16 consecutive halo pixels starting at pixel row hp0(i) (a
+    // multiple of 8, wave-uniform) + tap column dx.  Per-lane byte offset inside a halo image = faddr[dx] (pixel (lane & 15) + dx, chunk
+    // (lane >> 4) swizzled by bit 2 of that pixel row - hp0(i) does not touch bit 2) + foff(i) (wave-uniform: SGPR) + dy * LINE * 64 (immediate)
+    constexpr int NDX = HM == HM_CONV ? 3 : 1;
+    unsigned faddr[NDX];
+#pragma unroll
+    for (int dx = 0; dx < NDX; ++dx) {
+        const int hp = (lane & 15) + dx;
+        faddr[dx] = (unsigned)(HALO_OFF + hp * 64 + (((lane >> 4) ^ hswz(hp)) * 16));
+    }
+    auto foff = [&](int i) __attribute__((always_inline)) -> unsigned {
+        const int r = wm * WM + i * 16;
+        return (unsigned)((HM == HM_CONV ? (r / W_) * LINE + (r % W_) : r) * 64);
+    };
+    const unsigned zfrag = (unsigned)(ZERO_OFF + (lane & 15) * 64 + (lane >> 4) * 16);
+    int c_buf = 0;                                        // halo image of the chunk being consumed (its offset is folded into faddr)
+    unsigned vmask = 0;                                   // 3x3: bit (2 i) = fragment i may use dy = 0, bit (2 i + 1) = dy = 2 (same image)
+
+    // ---------------------------------------------------------------- prologue
+    for (int i = tid; i < 256; i += 512) reinterpret_cast<unsigned*>(lds + ZERO_OFF)[i] = 0u;
+    set_wtile(0);
+    // halo image 0 .. LA-1 of the first tile(s), normalised synchronously
+#pragma unroll 1
+    for (int pre = 0; pre < G::LA; ++pre) {
+        issue_halo();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // (zero page written; first pass only matters)
+        // (with NT <= XF0 the chain of an image runs beside the NEXT issue: the last image of the prologue is left to the loop's first chain)
+        if (XF && (G::XF0 < NT || pre + 1 < G::LA)) {
+            xf_begin();
+            static_for<0, HPW * 4 * 15>([&](auto o) { xf_op(o); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    {   // weight stages 0 .. NS-2: taps 0 .. NS-2 of chunk 0
+        static_for<0, NS - 1>([&](auto s_) { issue_w(decltype(s_)::value, decltype(s_)::value); });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    int rd = 0;                                           // ring slot of the current step
+    for (int it = 0; it < my_tiles; ++it) {
+        int tm;
+        long long e_n0;
+        tile_origin(it, tm, e_n0);
+        if (HM == HM_CONV) {
+            vmask = 0;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int fr = (int)(((long long)tm * BM + wm * WM + i * 16) / W_);
+                const int y = fr % H;
+                vmask |= (y > 0 ? 1u : 0u) << (2 * i);
+                vmask |= (y < H - 1 ? 1u : 0u) << (2 * i + 1);
+            }
+            vmask = (unsigned)__builtin_amdgcn_readfirstlane((int)vmask);
+        }
+        for (int c = 0; c < nchunks; ++c) {
+            static_for<0, NT>([&](auto tap_) {
+                constexpr int tap = decltype(tap_)::value;
+                constexpr int dy = HM == HM_CONV ? tap / 3 : tap, dx = HM == HM_CONV ? tap % 3 : 0;
+                constexpr int ltap = (tap + NS - 1) % NT;             // the weight loader's tap, NS-1 steps ahead
+                // ---- fragment reads of this step
+                {
+                    const unsigned char* sb = lds + RING_OFF + rd * WSTAGE + wfrag_off;
+                    // (the per-fragment sums below are loop invariants the compiler would otherwise hoist out of the nine tap bodies and keep in
+                    // 30 registers; an opaque copy of the base pins them to the step)
+                    unsigned fb = faddr[dx];
+                    asm volatile("" : "+v"(fb));
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) {
+                        unsigned a = fb + foff(i);
+                        if (HM == HM_CONV && dy != 1) {
+                            const bool ok = (vmask >> (2 * i + (dy == 2 ? 1 : 0))) & 1u;
+                            a = ok ? a : zfrag - (unsigned)(dy * LINE * 64);
+                        }
+                        xf[i] = *reinterpret_cast<const bf16x8*>(lds + a + dy * LINE * 64);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * ROWB);
+                }
+                // ---- loaders: the halo image LA chunks ahead (first step of a chunk), then the weights 3 steps ahead
+                if constexpr (tap == G::XF0 % NT) xf_begin();     // (ahead of this step's issue: with NT <= XF0 the chain belongs to the PREVIOUS issue)
+                if constexpr (tap == 0) issue_halo();
+                if constexpr (ltap == 0) {                            // the weight cursor enters the next chunk
+                    if (++w_c == nchunks) {
+                        w_c = 0;
+                        set_wtile(++w_it);
+                    }
+                }
+                issue_w(rd == 0 ? NS - 1 : rd - 1, ltap);
+                rd = (rd + 1 == NS) ? 0 : rd + 1;
+                // DMA ops younger than the pieces of the NEXT step's weight stage (issued two steps ago): two weight stages, plus the halo
+                // pieces + table piece when one of the last two issue points was a chunk's first step (they are issued AHEAD of that step's weights)
+                constexpr int HL = (tap == 0 || tap == 1) ? HPW + (XF ? 1 : 0) : 0;
+                if (grp == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 + HL) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(1);
+                // ---- 30 MFMAs, one instruction of the normalisation chain per issue slot
+                constexpr int XSTEP = ((tap - G::XF0) % NT + NT) % NT;    // (3x3: taps 3..7 carry the chain of the image issued at tap 0)
+                constexpr int NOPS = HPW * 4 * 15, NSLOT = G::XFN * 30;
+                static_for<0, MF * NF>([&](auto n_) {
+                    constexpr int n = decltype(n_)::value, i = n / NF, j = n % NF;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                    if constexpr (XF && XSTEP >= 0 && XSTEP < G::XFN) {
+                        constexpr int s0 = XSTEP * 30 + n;
+                        constexpr int o0 = (s0 * NOPS) / NSLOT, o1 = ((s0 + 1) * NOPS) / NSLOT;
+                        static_for<o0, o1>([&](auto o) { xf_op(o); });
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (its in-place ds_writes are inline asm)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 3 + HL) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            {   // next chunk reads the next halo image
+                const unsigned d = c_buf + 1 == NBUF ? (unsigned)(-(NBUF - 1) * HBYTES) : (unsigned)HBYTES;
+                c_buf = c_buf + 1 == NBUF ? 0 : c_buf + 1;
+#pragma unroll
+                for (int dx = 0; dx < NDX; ++dx) faddr[dx] += d;
+            }
+        }
+        // ---------------- tile finished for this group: retire it (v3 epilogue: 16-row chunks through the wave's staging region)
+        {
+            long long mw0;
+            if (HM == HM_CONV) {
+                mw0 = (long long)tm * BM + wm * WM;
+            } else {
+                const int sb = tm % sblocks, tb = (tm / sblocks) % tblocks, b = tm / (sblocks * tblocks);
+                mw0 = ((long long)b * p.T + tb * 6 + wm * 3) * p.S + sb * 32;      // first row of the wave's 3 frames x 32 positions
+            }
+            const long long nw0 = e_n0 + wn * WN;
+            float4 bv[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                bv[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + (int)nw0 + (lane >> 4) * 4 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool res_pre = p.res1 && !p.out_fp32 && (p.ldr1 % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res1) % 16 == 0);
+            GnAcc<GN ? NF : 1> gn;
+            if constexpr (GN) gn_zero(gn);
+            // a fragment's 16 rows are consecutive in both modes (3x3: flat pixels; temporal: 16 of the 32 positions of one frame)
+            auto frag_row0 = [&](int f) __attribute__((always_inline)) -> long long {
+                return HM == HM_CONV ? mw0 + f * 16 : mw0 + (long long)(f / 2) * p.S + (f % 2) * 16;
+            };
+            u32x4 n0 = {0u, 0u, 0u, 0u}, n1 = n0, n2 = n0;
+            if (res_pre) {
+                n0 = load_res_piece<0, 1, NF, false>(p, frag_row0(0), nw0, lane);
+                n1 = load_res_piece<1, 1, NF, false>(p, frag_row0(0), nw0, lane);
+                n2 = load_res_piece<2, 1, NF, false>(p, frag_row0(0), nw0, lane);
+            }
+            static_for<0, MF>([&](auto f_) {
+                constexpr int f = decltype(f_)::value;
+                const long long m0f = frag_row0(f);
+                const u32x4 r0 = n0, r1 = n1, r2 = n2;
+                if constexpr (f + 1 < MF) {
+                    if (res_pre) {       // residual rows one fragment ahead of their use (gemm.hip v3_retire_chunks)
+                        n0 = load_res_piece<0, 1, NF, false>(p, frag_row0(f + 1), nw0, lane);
+                        n1 = load_res_piece<1, 1, NF, false>(p, frag_row0(f + 1), nw0, lane);
+                        n2 = load_res_piece<2, 1, NF, false>(p, frag_row0(f + 1), nw0, lane);
+                    }
+                }
+                epilogue<1, NF, false, true, true, 16, GN>(p, *reinterpret_cast<f32x4(*)[1][NF]>(&acc[f]), m0f, nw0, 0, lane, estage, r0, r1, r2, res_pre, bv, true, &gn);
+                if constexpr (GN) {
+                    // writer = this wave tile's run of rows inside one statistics group; its slot is unique inside the group (gemm_common.h gn_flush)
+                    const long long sid = m0f / p.gn_rps;
+                    bool flush = f + 1 == MF;
+                    unsigned slot;
+                    if (HM == HM_CONV) {
+                        flush = flush || (m0f + 16) / p.gn_rps != sid;
+                        const long long first = mw0 / p.gn_rps == sid ? mw0 - sid * p.gn_rps : 0;
+                        slot = (unsigned)((first + WM - 1) / WM);
+                    } else {
+                        // temporal tiles: the host only offers the statistics epilogue for the 3-D GroupNorm (gn_rps = T * S: the wave's 3 frames
+                        // x 32 positions lie in one group); writer index inside the sample = (frame block, position block, wave row)
+                        const int sb = tm % sblocks, tb = (tm / sblocks) % tblocks;
+                        slot = (unsigned)((tb * sblocks + sb) * 2 + wm);
+                    }
+                    if (flush) gn_flush<NF>(p, gn, sid, nw0, lane, estage, slot);
+                }
+            });
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------------
+// 0 = this launch is not one of the haloed kernels' shapes (the caller keeps its v3d_gemm path), else the HaloGeom variant id
+int v3d_conv_halo_variant(const V3dGemmParams& p, int mode) {
+    auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
+    if (p.N % 320 || p.K % 32 || p.K * 2 > 65536 || p.out_fp32 || p.split_n > 1) return 0;
+    if (p.A2 && (p.K1 <= 0 || p.K1 >= p.K || p.K1 % 32 || p.lda2 % 8 || !al(p.A2, 16))) return 0;
+    if (p.ldo % 8 || !al(p.out, 16)) return 0;
+    if (p.add && (!al(p.add, 16) || p.add_ld % 4)) return 0;
+    if (p.res1 && (!al(p.res1, 16) || p.ldr1 % 8)) return 0;
+    if (p.res2 && (!al(p.res2, 8) || p.ldr2 % 4)) return 0;
+    if (p.bias && !al(p.bias, 16)) return 0;
+    if (p.gn_in && (p.gn_in_rps <= 0 || !al(p.gn_in, 16))) return 0;
+    if (p.gn_stats && (80 % p.gn_cpg || p.gn_rps % 16)) return 0;
+    if (mode == V3D_GEMM_CONV3X3) {
+        if (p.stride != 1 || p.upshift != 0 || p.pad_lo != 1 || p.Hin != p.Hout || p.Win != p.Wout) return 0;
+        if (p.M % 192) return 0;
+        const int W = p.Wout, H = p.Hout;
+        if (W != 64 && W != 32 && W != 16) return 0;
+        if (H < 192 / W + 1) return 0;                              // a halo (tile rows + 2 lines) touches at most two images
+        if (p.gn_in && p.gn_in_rps != (long long)H * W) return 0;   // one (scale, shift) row per image: the 2-D GroupNorm of the ResBlocks
+        if (p.gn_stats && p.gn_nslots < p.gn_rps / 96 + 2) return 0;
+        return W == 64 ? 1 : (W == 32 ? 2 : 3);
+    }
+    if (mode == V3D_GEMM_CONVT3) {
+        if (p.T % 6 || p.S % 32 || p.M % ((long long)p.T * p.S)) return 0;
+        if (p.gn_in && p.gn_in_rps != (long long)p.T * p.S) return 0;      // the 3-D GroupNorm: one row per sample
+        if (p.gn_stats && (p.gn_rps != (long long)p.T * p.S || p.gn_nslots < (p.T / 6) * (p.S / 32) * 2)) return 0;
+        return 4;
+    }
+    return 0;
+}
+
+template <int HM, int W_>
+static int conv_halo_launch_t(const V3dGemmParams& p0, hipStream_t st) {
+    V3dGemmParams p = p0;
+    p.mt = (int)(p.M / 192);
+    p.nt = (int)(p.N / 320);
+    const int ntiles = p.mt * p.nt;
+    const int grid = ntiles < v3d_num_cus() ? ntiles : v3d_num_cus();
+    const bool xf = p.gn_in != nullptr, gn = p.gn_stats != nullptr;
+    if (xf && gn) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
+    else if (xf) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, false>), dim3(grid), dim3(512), 0, st, p, ntiles);
+    else if (gn) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, false, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
+    else hipLaunchKernelGGL((conv_halo_kernel<HM, W_, false, false>), dim3(grid), dim3(512), 0, st, p, ntiles);
+    return v3d_check_launch("v3d_gemm(haloed)");
+}
+
+int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 1: return conv_halo_launch_t<HM_CONV, 64>(p, st);
+        case 2: return conv_halo_launch_t<HM_CONV, 32>(p, st);
+        case 3: return conv_halo_launch_t<HM_CONV, 16>(p, st);
+        case 4: return conv_halo_launch_t<HM_TEMP, 32>(p, st);
+    }
+    v3d_set_error("v3d_gemm(haloed): unknown variant %d", variant);
+    return V3D_ERR_ARG;
+}
+

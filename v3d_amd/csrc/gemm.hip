@@ -21,7 +21,7 @@
 #include <mutex>
 #include <type_traits>
 
-#include "common.h"
+#include "gemm_common.h"
 
 // Tile walk / tap order knobs (same-box A/B: tools/gemm_ab.sh, profiles/r02b_gemm_ab.txt):
 //   V3D_GEMM_GROUPM   -1 heuristic (default), 0 = row-major walk, n = groups of n tile rows.  Measured (TF/s, row-major -> 4 -> 8): GEGLU projection
@@ -36,464 +36,9 @@
 
 namespace {
 
-// compile-time loop (bodies that pick between named register arrays must not wait for the late loop unroller: SROA has
-// already given up on the arrays by then and they land in scratch)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-struct GP {
-    const bf16_t* A;
-    const bf16_t* W;
-    void* out;
-    const float* bias;
-    const float* add;
-    const bf16_t* res1;
-    const bf16_t* res2;
-    const float* coef;
-    long long M, N, K;
-    long long lda, ldw, ldo, ldr1, ldr2;
-    long long add_rpg, add_ld, coef_rpg;
-    float c_acc, c_res1, c_res2;
-    int out_fp32;
-    long long a_row0;
-    unsigned a_bytes, w_bytes;
-    int Hin, Win, Hout, Wout, stride, upshift;
-    int pad_lo;          // zero pixels before the first row / column (1, or 0 for the asymmetric right/bottom padding)
-    int T, tmin, tmax;
-    long long S;
-    long long halo_rows; // CONVT3 split-halo layout (0 = dense)
-    long long sA, sW, sO;
-    int mt, nt;  // tile counts
-    int group_m;         // tile walk: > 1 = ids run down groups of `group_m` tile rows first (L2-friendly patches), else row-major over N
-    int tap_inner;       // multi-tap modes: 1 = stage order (k outer, tap inner): the taps re-read an activation tile while it is still in L2
-    int split_n;         // > 1: split-K launch: blockIdx.y = split index = output slab (out = fp32 workspace [split][M][N], plain stores)
-    const float* ws;     // finalize kernel only: the workspace to reduce
-    int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads
-    float* gn_stats;     // GroupNorm partial sums of the output [M / gn_rps][V3D_GN_SLOTS][32][2], accumulated by the v3 <GN> epilogue (else NULL)
-    long long gn_rps;    // rows per statistics group
-    int gn_cpg;          // channels per group (N / 32)
-};
-
 // 64 KiB of zeros: an invalid (padding / tail) lane of the LDS-DMA points here and can still be advanced by k0 like a
 // real row pointer (K * 2 bytes <= 64 KiB is checked on the host), so the main loop has no per-step selects.
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[16384] = {0};
-
-template <int MODE>
-struct RowInfo {};
-
-template <>
-struct RowInfo<V3D_GEMM_LINEAR> {
-    long long src;
-    bool ok;
-    __device__ void init(const GP& p, long long m) {
-        ok = m < p.M;
-        src = m;
-    }
-    __device__ bool tap(const GP&, int, long long& s) const {
-        s = src;
-        return ok;
-    }
-};
-
-template <>
-struct RowInfo<V3D_GEMM_CONV3X3> {
-    long long base;
-    int iy0, ix0;
-    bool ok;
-    __device__ void init(const GP& p, long long m) {
-        ok = m < p.M;
-        long long hw = (long long)p.Hout * p.Wout;
-        long long img = m / hw;
-        int rem = (int)(m - img * hw);
-        int oy = rem / p.Wout;
-        int ox = rem - oy * p.Wout;
-        base = img * (long long)p.Hin * p.Win;
-        iy0 = oy * p.stride - p.pad_lo;
-        ix0 = ox * p.stride - p.pad_lo;
-    }
-    __device__ bool tap(const GP& p, int t, long long& s) const {
-        int ky = t / 3, kx = t - ky * 3;
-        int iy = iy0 + ky, ix = ix0 + kx;
-        bool v = ok && iy >= 0 && ix >= 0 && iy < (p.Hin << p.upshift) && ix < (p.Win << p.upshift);
-        s = base + (long long)(iy >> p.upshift) * p.Win + (ix >> p.upshift);
-        return v;
-    }
-};
-
-template <>
-struct RowInfo<V3D_GEMM_CONVT3> {
-    long long m_;
-    long long hoff_;   // split-halo layout only: b * S + s, the row of this (sample, position) inside a halo slab
-    int t_;
-    bool ok;
-    __device__ void init(const GP& p, long long m) {
-        ok = m < p.M;
-        m_ = m;
-        long long frame = m / p.S;
-        t_ = (int)(frame % p.T);
-        hoff_ = (frame / p.T) * p.S + (m - frame * p.S);
-    }
-    __device__ bool tap(const GP& p, int t, long long& s) const {
-        int tt = t_ + t - 1;
-        s = m_ + (long long)(t - 1) * p.S;
-        // frame sharding (halo_rows = B * S): frame -1 of every sample lives in the slab in FRONT of the local frames, frame T in
-        // the slab BEHIND them, so the +-1 frames of a sample never alias the neighbouring sample's frames and all B samples of
-        // a rank go through one launch
-        if (p.halo_rows > 0) {
-            if (tt < 0) s = hoff_ - p.halo_rows;
-            else if (tt >= p.T) s = p.M + hoff_;
-        }
-        return ok && tt >= p.tmin && tt <= p.tmax;
-    }
-};
-
-template <int MODE>
-constexpr int ntaps() {
-    return MODE == V3D_GEMM_LINEAR ? 1 : (MODE == V3D_GEMM_CONV3X3 ? 9 : 3);
-}
-
-// XCD-aware bijective remap of a 1-D grid: consecutive logical tiles share an XCD (and its L2)
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-
-// tile id -> (tile row, tile column).  Consecutive ids run concurrently on one XCD (xcd_remap), i.e. share one 4 MiB L2: walking N fastest
-// makes 32-64 concurrent tiles of ONE tile row re-stream the whole weight matrix per row of tiles (PMC, profiles/r02a_pmc_per_launch.txt:
-// the N = 10240 GEGLU projection fetched 20x its algorithmic bytes).  group_m > 1 walks down `group_m` tile rows before moving to the next
-// tile column, so the concurrent set is a group_m x (concurrency / group_m) patch that shares both operands; bijective for any mt, nt.
-__device__ __forceinline__ void tile_coords(const GP& p, int id, int& tm, int& tn) {
-    const int gm = p.group_m >= 0 ? p.group_m : (p.mt >= 96 ? 8 : 4);     // < 0: heuristic (see the knob comment at the top)
-    if (gm <= 1 || p.nt == 1) {
-        tn = id % p.nt;
-        tm = id / p.nt;
-        return;
-    }
-    const int width = gm * p.nt;
-    const int gid = id / width;
-    const int first = gid * gm;
-    const int gsz = (p.mt - first) < gm ? (p.mt - first) : gm;
-    const int r = id - gid * width;
-    tn = r / gsz;
-    tm = first + (r - tn * gsz);
-}
-
-// ---- epilogue shared by both main loops --------------------------------------------------------------------------
-// The wave holds MF x NF fragments; per fragment a lane owns 4 consecutive n (= (lane>>4)*4 + r) of pixel m = lane&15.
-// bf16 outputs are staged through a wave-private LDS region (`stage`, >= MF*16 rows of (WNout*2 + 16) bytes) and leave as
-// 16-byte-per-lane stores covering whole row segments.  Two code paths: a branch-free FAST path for wave tiles that lie
-// completely inside the output (every predicate is wave-uniform: float4 bias / per-image vector loads, 8-byte residual
-// loads, no per-element bounds checks) and the generic path with per-element predicates for ragged M / N edges.
-// (The first version had only the generic path: 1500 VALU + 380 exec-mask branches per wave against 160 MFMAs on the
-// K = 320 GEGLU GEMM, see profiles/r01_gemm_ablation.txt.)
-// residual #1 rows of one (MF*16) x (NFO*16) wave tile as coalesced 16-byte pieces (the layout the staging buffer uses):
-// piece K of lane l is chunk c = K*64 + l -> row c / CPRO, 16-byte column chunk c % CPRO.  The v3 kernels prefetch these one
-// epilogue chunk ahead and hand them over BY VALUE (a struct / array handed over by reference went through scratch).
-template <int MF, int NF, bool GEGLU>
-struct ResGeom {
-    static constexpr int NFO = GEGLU ? NF / 2 : NF;
-    static constexpr int CPRO = NFO * 2, ROWS = MF * 16, NV = (ROWS * CPRO + 63) / 64;
-};
-template <int K, int MF, int NF, bool GEGLU>
-__device__ __forceinline__ u32x4 load_res_piece(const GP& p, long long mw0, long long nw0, int lane) {
-    using G = ResGeom<MF, NF, GEGLU>;
-    u32x4 r = {0u, 0u, 0u, 0u};
-    if constexpr (K < G::NV) {
-        const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;
-        const int c = K * 64 + lane;
-        if ((G::ROWS * G::CPRO) % 64 == 0 || c < G::ROWS * G::CPRO)
-            r = *reinterpret_cast<const u32x4*>(p.res1 + (mw0 + c / G::CPRO) * p.ldr1 + ncol0 + (c % G::CPRO) * 8);
-    }
-    return r;
-}
-template <int K, int MF, int NF, bool GEGLU>
-__device__ __forceinline__ void res_piece_to_stage(u32x4 r, unsigned char* stage, int srow, int lane) {
-    using G = ResGeom<MF, NF, GEGLU>;
-    if constexpr (K < G::NV) {
-        const int c = K * 64 + lane;
-        if ((G::ROWS * G::CPRO) % 64 == 0 || c < G::ROWS * G::CPRO) *reinterpret_cast<u32x4*>(stage + (c / G::CPRO) * srow + (c % G::CPRO) * 16) = r;
-    }
-}
-
-// ---- GroupNorm statistics of the output, gathered where it is produced (v3 <GN> kernels) ----------------------------------------
-// Every ResBlock convolution is followed by a GroupNorm of its output (openaimodel.py:267-271,302-305 / video_model.py:42-55); the
-// stand-alone statistics kernel re-reads that tensor from HBM.  Here a wave adds up (sum, sum of squares) of the bf16-ROUNDED values it
-// stores - the numbers v3d_groupnorm_stats would read back - per channel over the rows of its tile that belong to one statistics group
-// (rows / gn_rps: an image, or the T images of a sample for the 3-D norm): in registers over the row fragments, across the 16 pixel lanes
-// with DPP row shifts, through the wave's staging region to one lane per GroupNorm group, then 2 fp32 atomics per group into the same
-// [stat][slot][32][2] buffer the stand-alone kernel fills.
-template <int NF>
-struct GnAcc {
-    float s[NF][2], q[NF][2];     // per fragment column j: channel pairs (4 q + 0, 1) and (4 q + 2, 3) of the lane's 4 channels - groups hold an even
-};                                // number of channels, so a pair never straddles two of them
-template <int NF>
-__device__ __forceinline__ void gn_zero(GnAcc<NF>& a) {
-#pragma unroll
-    for (int j = 0; j < NF; ++j) a.s[j][0] = a.s[j][1] = a.q[j][0] = a.q[j][1] = 0.f;
-}
-// one packed bf16 pair of the stored tile: sum and sum of squares by v_dot2_f32_bf16 (exact products, fp32 accumulation, no unpacking)
-typedef __bf16 gn_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gn_add_pair(float& s, float& q, uint32_t w) {
-    const gn_bf16x2 v = __builtin_bit_cast(gn_bf16x2, w), ones = __builtin_bit_cast(gn_bf16x2, 0x3f803f80u);
-    s = __builtin_amdgcn_fdot2_f32_bf16(v, ones, s, false);
-    q = __builtin_amdgcn_fdot2_f32_bf16(v, v, q, false);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_row_shr(float v) {    // value of the lane CTRL positions below in the 16-lane row, 0 past the row start
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 | CTRL, 0xf, 0xf, true));
-}
-template <int NF>
-__device__ __forceinline__ void gn_flush(const GP& p, GnAcc<NF>& a, long long sid, long long nw0, int lane, unsigned char* stage, unsigned slot) {
-    float* sf = reinterpret_cast<float*>(stage);
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        f32x4 t = {a.s[j][0], a.s[j][1], a.q[j][0], a.q[j][1]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = t[e];
-            v += dpp_row_shr<1>(v);
-            v += dpp_row_shr<2>(v);
-            v += dpp_row_shr<4>(v);
-            v += dpp_row_shr<8>(v);     // lane 15 of each row: the row's total
-            t[e] = v;
-        }
-        // 4 lanes: channel pairs of channels j * 16 + (lane >> 4) * 4 .. + 3 of the wave tile, as {s01, s23, q01, q23}
-        if ((lane & 15) == 15) lds_store16_nowait(sf + (j * 4 + (lane >> 4)) * 4, t);
-    }
-    // one lane per GroupNorm group that intersects the wave tile's channels [nw0, nw0 + NF * 16)
-    const int cpg = p.gn_cpg;
-    const int g_lo = (int)(nw0 / cpg), g_hi = (int)((nw0 + NF * 16 - 1) / cpg);
-    const int g = g_lo + lane;
-    if (g <= g_hi) {
-        const int c0 = g * cpg > (int)nw0 ? g * cpg - (int)nw0 : 0;
-        const int c1 = (g + 1) * cpg - (int)nw0 < NF * 16 ? (g + 1) * cpg - (int)nw0 : NF * 16;
-        float sa = 0.f, sb = 0.f;
-        for (int cp = c0 >> 1; cp < (c1 >> 1); ++cp) {            // channel pair cp = channels 2 cp, 2 cp + 1 of the tile
-            const float* e = sf + (cp >> 1) * 4 + (cp & 1);
-            sa += e[0];
-            sb += e[2];
-        }
-        float* dst = p.gn_stats + ((sid * V3D_GN_SLOTS + slot) * 32 + g) * 2;
-        if (!(p.ablate & 1024)) {
-            atomicAdd(dst, sa);
-            atomicAdd(dst + 1, sb);
-        }
-    }
-    gn_zero(a);
-}
-
-template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false, int SPAD = 16, bool GN = false>
-__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
-                                         unsigned char* stage, u32x4 pre0, u32x4 pre1, u32x4 pre2, bool res_pre,
-                                         const float4 (&bias_pre)[NF], bool has_bias_pre, GnAcc<GN ? NF : 1>* gn = nullptr) {
-    if (p.ablate & 1) {
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (sum == 123.456f) reinterpret_cast<float*>(p.out)[0] = sum;   // keeps the accumulators live
-        return;
-    }
-    const long long Nout = GEGLU ? p.N / 2 : p.N;
-    constexpr int NFO = GEGLU ? NF / 2 : NF;          // output fragments per wave-tile row
-    constexpr int SROW = NFO * 32 + SPAD;             // staging row stride in bytes (16 B pad unless LDS is too tight)
-    const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;   // first output column of this wave tile
-    const bool staged = CAN_STAGE && !p.out_fp32 && (p.ldo % 8 == 0) && (ncol0 % 8 == 0) &&
-                        ((reinterpret_cast<uintptr_t>(p.out) + (size_t)z * p.sO * 2) % 16 == 0);
-    const bool vec_ok = (p.ldo % 4 == 0) && (!p.res1 || p.ldr1 % 4 == 0) && (!p.res2 || p.ldr2 % 4 == 0);
-    const bool fast = (mw0 + MF * 16 <= p.M) && (nw0 + NF * 16 <= p.N) && vec_ok && (staged || p.out_fp32) &&
-                      (!p.add || ((reinterpret_cast<uintptr_t>(p.add) % 16 == 0) && (p.add_ld % 4 == 0))) &&
-                      (!p.res1 || reinterpret_cast<uintptr_t>(p.res1) % 8 == 0) && (!p.res2 || reinterpret_cast<uintptr_t>(p.res2) % 8 == 0);
-    const int fr = lane & 15, fq = (lane >> 4) * 4;
-    if (FAST_ONLY && (mw0 >= p.M || nw0 >= p.N)) return;   // wave tile completely outside a partial edge tile
-    if (FAST_ONLY || fast) {   // FAST_ONLY: the host has checked the fast-path conditions for every wave tile (v3 kernels)
-        const int nb = (int)nw0 + fq;                  // this lane's first packed weight row (tile-relative math in 32 bit)
-        constexpr int CPRO = NFO * 2;                  // 16-byte chunks per staged row
-        constexpr int ROWS = MF * 16;
-        constexpr bool WHOLE = (ROWS * CPRO) % 64 == 0;   // else the last wave-wide copy of the staged tile is partial
-        // residual #1 comes in through the staging buffer: coalesced 16-byte row loads -> LDS, then each lane picks its 8 bytes in
-        // MFMA layout (the direct 8-byte-per-lane residual loads touched 16 rows per instruction: 129 us vs 70 us for the
-        // attention out-projection at 64x64, profiles/r01d_op_times_unet_eval.txt)
-        const bool res1_lds = CAN_STAGE && p.res1 && !p.out_fp32 && (p.ldr1 % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res1) % 16 == 0);
-        if (CAN_STAGE && res1_lds) {
-            if (res_pre) {   // (only offered by callers whose wave-tile chunk has at most 3 pieces per lane)
-                res_piece_to_stage<0, MF, NF, GEGLU>(pre0, stage, SROW, lane);
-                res_piece_to_stage<1, MF, NF, GEGLU>(pre1, stage, SROW, lane);
-                res_piece_to_stage<2, MF, NF, GEGLU>(pre2, stage, SROW, lane);
-            } else {
-                const bf16_t* rz = p.res1 + mw0 * p.ldr1 + ncol0;
-                uint4 rv[(ROWS * CPRO + 63) / 64];
-#pragma unroll
-                for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
-                    const int c = c0 + lane;
-                    if (WHOLE || c < ROWS * CPRO) rv[c0 / 64] = *reinterpret_cast<const uint4*>(rz + (long long)(c / CPRO) * p.ldr1 + (c % CPRO) * 8);
-                }
-#pragma unroll
-                for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
-                    const int c = c0 + lane;
-                    if (WHOLE || c < ROWS * CPRO) *reinterpret_cast<uint4*>(stage + (c / CPRO) * SROW + (c % CPRO) * 16) = rv[c0 / 64];
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        const bool scale_acc = p.coef != nullptr || p.c_acc != 1.0f;   // wave-uniform
-        float4 bv[NF];
-        if (has_bias_pre) {   // the caller loaded this wave tile's bias columns once for all of its row chunks
-#pragma unroll
-            for (int j = 0; j < NF; ++j) bv[j] = bias_pre[j];
-        } else if (p.bias) {
-#pragma unroll
-            for (int j = 0; j < NF; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + nb + j * 16);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NF; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const long long m = mw0 + i * 16 + fr;
-            float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
-            if (p.coef) {
-                const float* cf = p.coef + (m / p.coef_rpg) * 3;
-                ca = cf[0]; c1 = cf[1]; c2 = cf[2];
-            }
-            const float* addv = p.add ? p.add + (m / p.add_rpg) * p.add_ld + nb : nullptr;
-            const bf16_t* r1 = (p.res1 && !res1_lds) ? p.res1 + m * p.ldr1 + (int)ncol0 + fq : nullptr;
-            const bf16_t* r2 = p.res2 ? p.res2 + m * p.ldr2 + (int)ncol0 + fq : nullptr;
-            float* of = p.out_fp32 ? reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + (int)ncol0 + fq : nullptr;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                if (GEGLU && (j & 1)) continue;
-                float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
-                if (addv) {
-                    const float4 a = *reinterpret_cast<const float4*>(addv + j * 16);
-                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-                }
-                if (GEGLU) {
-                    constexpr int dummy = 0;
-                    const int jg = (j + 1 < NF) ? j + 1 : j;
-                    float g[4] = {acc[i][jg][0] + bv[jg].x, acc[i][jg][1] + bv[jg].y, acc[i][jg][2] + bv[jg].z, acc[i][jg][3] + bv[jg].w};
-                    if (addv) {
-                        const float4 a = *reinterpret_cast<const float4*>(addv + jg * 16);
-                        g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (p.ablate & 16) ? v[r] * g[r] : geglu_mul(v[r], g[r]);
-                    (void)dummy;
-                }
-                const int jo = GEGLU ? (j >> 1) : j;
-                float o[4] = {v[0], v[1], v[2], v[3]};
-                if (scale_acc) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] *= ca;
-                }
-                if (CAN_STAGE && res1_lds) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2);
-                    o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
-                } else if (r1) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(r1 + jo * 16);
-                    o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
-                }
-                if (r2) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(r2 + jo * 16);
-                    o[0] += c2 * bflo(rr.x); o[1] += c2 * bfhi(rr.x); o[2] += c2 * bflo(rr.y); o[3] += c2 * bfhi(rr.y);
-                }
-                if (of) {
-                    *reinterpret_cast<float4*>(of + jo * 16) = make_float4(o[0], o[1], o[2], o[3]);
-                } else if (CAN_STAGE) {
-                    const uint32_t w0 = pack2bf(o[0], o[1]), w1 = pack2bf(o[2], o[3]);
-                    *reinterpret_cast<uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2) = make_uint2(w0, w1);
-                    if constexpr (GN) {
-                        gn_add_pair(gn->s[j][0], gn->q[j][0], w0);
-                        gn_add_pair(gn->s[j][1], gn->q[j][1], w1);
-                    }
-                }
-            }
-        }
-        if (CAN_STAGE && !p.out_fp32) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            bf16_t* outz = reinterpret_cast<bf16_t*>(p.out) + z * p.sO + mw0 * p.ldo + ncol0;
-#pragma unroll
-            for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
-                const int c = c0 + lane;
-                const int row = c / CPRO, ch = c % CPRO;
-                if ((WHOLE || c < ROWS * CPRO) && !(p.ablate & 32)) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
-            }
-        }
-        return;
-    }
-    if (FAST_ONLY) return;
-    // ---------------- generic path (ragged edges) ----------------
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const long long m = mw0 + i * 16 + fr;
-        if (m >= p.M) continue;
-        float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
-        if (p.coef) {
-            const float* cf = p.coef + (m / p.coef_rpg) * 3;
-            ca = cf[0];
-            c1 = cf[1];
-            c2 = cf[2];
-        }
-        const float* addv = p.add ? p.add + (m / p.add_rpg) * p.add_ld : nullptr;
-#pragma unroll
-        for (int j = 0; j < NF; j += 1) {
-            if (GEGLU && (j & 1)) continue;  // gate fragments are consumed with their value fragment
-            const long long np = nw0 + j * 16 + fq;  // packed weight-row index
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r];
-                if (np + r < p.N) {
-                    if (p.bias) v[r] += p.bias[np + r];
-                    if (addv) v[r] += addv[np + r];
-                }
-            }
-            long long col = np;
-            if (GEGLU) {
-                const int jg = (j + 1 < NF) ? j + 1 : j;
-                const long long ng = np + 16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float g = acc[i][jg][r];
-                    if (ng + r < p.N) {
-                        if (p.bias) g += p.bias[ng + r];
-                        if (addv) g += addv[ng + r];
-                    }
-                    v[r] = v[r] * gelu_erf_f(g);
-                }
-                col = (np >> 5) * 16 + (np & 15);
-            }
-            if (col >= Nout) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (col + r < Nout) {
-                    float o = ca * v[r];
-                    if (p.res1) o += c1 * bf2f(p.res1[m * p.ldr1 + col + r]);
-                    if (p.res2) o += c2 * bf2f(p.res2[m * p.ldr2 + col + r]);
-                    if (p.out_fp32)
-                        (reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + col)[r] = o;
-                    else
-                        (reinterpret_cast<bf16_t*>(p.out) + z * p.sO + m * p.ldo + col)[r] = f2bf(o);
-                }
-            }
-        }
-    }
-}
-
-template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false>
-__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
-                                         unsigned char* stage) {
-    const u32x4 none = {0u, 0u, 0u, 0u};
-    float4 nob[NF];
-    epilogue<MF, NF, GEGLU, CAN_STAGE, FAST_ONLY>(p, acc, mw0, nw0, z, lane, stage, none, none, none, false, nob, false);
-}
 
 // =====================================================================================================================
 // v2: LDS-DMA ring pipeline
@@ -624,7 +169,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN) == 256 ? 2 : 1) vo
 
     // main-loop waves outrank co-resident blocks that are in their (VALU-dense) epilogue: without it the two do not overlap -
     // time(K) = time(epilogue only) + time(main loop only) on the GEGLU projections (tools/gemm_floor.py)
-    if (!(p.ablate & 64)) __builtin_amdgcn_s_setprio(2);
+    if (!V3D_ABL(p, 64)) __builtin_amdgcn_s_setprio(2);
     for (int t = 0; t < nsteps; ++t) {
         // this wave's pieces of stage t have landed when at most PIECES*(NS-2) newer DMA ops are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (NS - 2)) : "memory");
@@ -775,35 +320,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v1(GP p) {
 //     the ring keeps prefetching across tile boundaries and a group's epilogue overlaps the other group's MFMA slot.
 //   * counted s_waitcnt vmcnt(8): two younger stages (4 DMA ops each per wave) may stay in flight; epilogue stores in
 //     flight only make the count conservative (loads return in order among themselves).
-// retire the finished tile of a v3 wave in chunks of EMF row fragments; residual rows come in one chunk ahead of their use
-// (a per-chunk load -> LDS -> use chain exposed the full load latency 8 times per tile: the [bar] out-projections ran
-// 15-50 % slower than on v2)
-template <int C, int NCH, int EMF, int NF, bool GEGLU, int SPAD, bool GN>
-__device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH * EMF][NF], long long mw0, long long nw0, int lane, unsigned char* estage,
-                                                 u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre, const float4 (&bv)[NF], GnAcc<GN ? NF : 1>& gn,
-                                                 long long sid0, unsigned rem0) {
-    static_assert(ResGeom<EMF, NF, GEGLU>::NV <= 3, "v3 epilogue chunk: at most 3 residual pieces per lane");
-    if constexpr (C < NCH) {
-        u32x4 n0 = c0, n1 = c1, n2 = c2;
-        if constexpr (C + 1 < NCH) {
-            if (res_pre) {
-                n0 = load_res_piece<0, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
-                n1 = load_res_piece<1, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
-                n2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
-            }
-        }
-        epilogue<EMF, NF, GEGLU, true, true, SPAD, GN>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true, &gn);
-        if constexpr (GN) {
-            // rows of this chunk belong to statistics group sid0 + (rem0 + C * 16) / gn_rps; hand the sums over when the next chunk
-            // starts another group (a tile may straddle images: 4096 rows per image, 96 per wave tile) or the tile ends
-            static_assert(EMF == 1, "GN epilogue: one row fragment per chunk");
-            const unsigned rps = (unsigned)p.gn_rps;
-            const unsigned here = (rem0 + C * 16) / rps, next = (rem0 + (C + 1) * 16) / rps;
-            if (C + 1 == NCH || next != here) gn_flush<NF>(p, gn, sid0 + here, nw0, lane, estage, (unsigned)((mw0 >> 4) + C + (nw0 >> 4)) % V3D_GN_SLOTS);
-        }
-        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU, SPAD, GN>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre, bv, gn, sid0, rem0);
-    }
-}
 
 // slot-level timeline of the v3 loop (V3D_GEMM_ABLATE bit 8, LINEAR only): [group][step 32..63][stamp] s_memtime ticks
 __device__ unsigned long long g_v3_dbg[2 * 32 * 8];
@@ -887,11 +403,11 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     };
     set_tile(0);
     auto issue_piece = [&](int stage, int i) __attribute__((always_inline)) {
-        if (p.ablate & 4) return;
+        if V3D_ABL(p, 4) return;
         const int q = wave + NW * i;
         // experiment (bit 2048): activation pieces issued out of range - same DMA op count, zeros instead of an L2 fetch: what the L2->LDS bytes
         // of the activation operand cost (a lower bound of what an LDS-resident halo tile would save a 3x3 convolution)
-        const unsigned vo = ((p.ablate & 2048) && q < APIECES) ? kInvalid : voff[i];
+        const unsigned vo = (V3D_ABL(p, 2048) && q < APIECES) ? kInvalid : voff[i];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)vo, ld_k0 * 2, 0, 0);
     };
     auto issue_advance = [&]() __attribute__((always_inline)) {
@@ -969,7 +485,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
             stamp(s, 1);
             // group 1 must have its fragments in registers before it passes the barrier (the slot is refilled after it);
             // group 0 goes straight into its MFMAs and lets the compiler's counted lgkmcnt waits release them fragment by fragment
-            if (grp == 1 || (p.ablate & 512)) {
+            if (grp == 1 || V3D_ABL(p, 512)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -980,15 +496,15 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
                 __builtin_amdgcn_sched_barrier(0);
             }
             stamp(s, 3);
-            if (!(p.ablate & 256)) __builtin_amdgcn_s_setprio(1);
-            if (!(p.ablate & 2)) {
+            if (!V3D_ABL(p, 256)) __builtin_amdgcn_s_setprio(1);
+            if (!V3D_ABL(p, 2)) {
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
             }
-            if (!(p.ablate & 256)) __builtin_amdgcn_s_setprio(0);
+            if (!V3D_ABL(p, 256)) __builtin_amdgcn_s_setprio(0);
             stamp(s, 4);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) {
@@ -1284,7 +800,7 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
     const int ntiles = p.mt * p.nt;
     const int grid = ntiles < v3d_num_cus() ? ntiles : v3d_num_cus();
     if constexpr (MODE == V3D_GEMM_LINEAR && !GEGLU) {
-        if (p.ablate & 8) {
+        if V3D_ABL(p, 8) {
             hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
@@ -1298,7 +814,9 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
     }
     if constexpr (!GEGLU) {
         if (variant == 1) {   // the N = 320 family: 192 x 320 tile, wave tile 96 x 80 (147456 rows = 768 tiles = 3 per CU)
-            if (p.gn_stats) {
+            // statistics epilogue: every writer (wave tile x statistics group) stores into its own slot - needs whole groups per wave column
+            // and gn_rps / (wave tile rows) + 2 slots
+            if (p.gn_stats && 80 % p.gn_cpg == 0 && p.gn_nslots >= p.gn_rps / 96 + 2) {
                 g_gn_in_epilogue = true;
                 ++g_gn_epilogue_launches;
                 hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
@@ -1307,7 +825,7 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
             }
             return v3d_check_launch("v3d_gemm");
         }
-        if (p.gn_stats) {
+        if (p.gn_stats && variant == 0 && 64 % p.gn_cpg == 0 && p.gn_nslots >= p.gn_rps / 128 + 2) {
             g_gn_in_epilogue = true;
             ++g_gn_epilogue_launches;
             hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
@@ -1319,7 +837,7 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
         // 128-byte lines of every output row (the 2 x 4 layout wrote 64-byte half lines from two different waves)
         // measured (tools/gemm_floor.py, M = 147456, N = 2560): K = 320: 396 us vs 416 us (2 x 4) vs 402 us (two 256 x 128 blocks
         // per CU) vs 421 us (v2); at K >= 640 the 2 x 4 layout with 32-row chunks is ahead again (tools/gemm_sweep.py)
-        if (p.K < 640 && !(p.ablate & 128)) {
+        if (p.K < 640 && !V3D_ABL(p, 128)) {
             hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 4, 2, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
@@ -1374,7 +892,9 @@ namespace {
 int run_mode(const v3d_gemm_args* a, GP& p, hipStream_t st);
 }
 
-extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
+namespace {
+// argument checks + the kernels' parameter block; *halo = the LDS-haloed kernel variant that takes the launch (conv.hip), 0 = none
+int fill_params(const v3d_gemm_args* a, GP& p, int* halo) {
     V3D_REQUIRE(a != nullptr, "v3d_gemm: null args");
     V3D_REQUIRE(a->A && a->W && a->out, "v3d_gemm: null A/W/out");
     V3D_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "v3d_gemm: bad M/N/K (%lld,%lld,%lld)", (long long)a->M, (long long)a->N, (long long)a->K);
@@ -1395,7 +915,6 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     const unsigned long long a_bytes = (unsigned long long)a->a_rows * a->lda * 2ull;
     const unsigned long long w_bytes = ((unsigned long long)(taps * a->N - 1) * ldw + a->K) * 2ull;
     V3D_REQUIRE(a_bytes <= kMaxBufBytes && w_bytes <= kMaxBufBytes, "v3d_gemm: operand larger than 4 GiB - 256 B (A %llu B, W %llu B)", a_bytes, w_bytes);
-    GP p;
     p.A = (const bf16_t*)a->A; p.W = (const bf16_t*)a->W; p.out = a->out;
     p.bias = a->bias; p.add = a->add; p.res1 = (const bf16_t*)a->res1; p.res2 = (const bf16_t*)a->res2; p.coef = a->coef;
     p.M = a->M; p.N = a->N; p.K = a->K;
@@ -1420,22 +939,71 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     }
     p.split_n = 1;
     p.ws = nullptr;
+    p.ablate = 0;
+#ifdef V3D_EXPERIMENTS
     { static int ab = -1; if (ab < 0) { const char* e = getenv("V3D_GEMM_ABLATE"); ab = e ? atoi(e) : 0; } p.ablate = ab; }
-    hipStream_t st = (hipStream_t)stream;
-    p.gn_stats = nullptr; p.gn_rps = 0; p.gn_cpg = 0;
+#endif
+    p.gn_stats = nullptr; p.gn_rps = 0; p.gn_cpg = 0; p.gn_nslots = 0;
     if (a->gn_stats) {
         V3D_REQUIRE(!a->geglu && !a->out_fp32 && a->batch == 1, "v3d_gemm: gn_stats needs a bf16, non-GEGLU, unbatched output");
         V3D_REQUIRE(a->gn_cpg > 0 && a->gn_cpg % 2 == 0 && a->N == 32ll * a->gn_cpg, "v3d_gemm: gn_stats needs N = 32 * gn_cpg (got N=%lld cpg=%d)", (long long)a->N, a->gn_cpg);
         V3D_REQUIRE(a->gn_rps >= 16 && a->gn_rps % 16 == 0 && a->gn_rps < (1ll << 30) && a->M % a->gn_rps == 0, "v3d_gemm: gn_rps must be a multiple of 16 that divides M");
-        V3D_REQUIRE(a->ldo == a->N && ((uintptr_t)a->gn_stats & 3) == 0, "v3d_gemm: gn_stats needs a dense output (ldo == N)");
+        V3D_REQUIRE(a->ldo == a->N && ((uintptr_t)a->gn_stats & 7) == 0, "v3d_gemm: gn_stats needs a dense output (ldo == N) and an 8-byte aligned buffer");
+        V3D_REQUIRE(a->gn_nslots >= 1, "v3d_gemm: gn_nslots must be >= 1");
         static int ep = -1;
         if (ep < 0) { const char* e = getenv("V3D_GEMM_GN_EPILOGUE"); ep = e ? atoi(e) : 1; }      // A/B knob: 0 = always the stand-alone statistics kernel
-        if (ep) { p.gn_stats = a->gn_stats; p.gn_rps = a->gn_rps; p.gn_cpg = a->gn_cpg; }
+        if (ep) { p.gn_stats = a->gn_stats; p.gn_rps = a->gn_rps; p.gn_cpg = a->gn_cpg; p.gn_nslots = a->gn_nslots; }
+    }
+    // GroupNorm (+SiLU) of the input in the operand path / two-source input: only the LDS-haloed kernels (conv.hip) take these
+    p.A2 = (const bf16_t*)a->A2; p.K1 = a->A2 ? a->K1 : a->K; p.lda2 = a->lda2; p.a2_bytes = 0;
+    p.gn_in = a->gn_in_table; p.gn_in_rps = a->gn_in_rps; p.gn_in_silu = a->gn_in_silu; p.gn_in_bytes = 0;
+    if (a->A2) {
+        V3D_REQUIRE(a->gn_in_table != nullptr, "v3d_gemm: a two-source input (A2) is only defined together with gn_in_table");
+        const unsigned long long a2b = (unsigned long long)a->a_rows * a->lda2 * 2ull;
+        V3D_REQUIRE(a->lda2 >= a->K - a->K1 && a2b <= kMaxBufBytes, "v3d_gemm: bad lda2 / A2 larger than 4 GiB - 256 B");
+        p.a2_bytes = (unsigned)a2b;
+    }
+    if (a->gn_in_table) {
+        V3D_REQUIRE(a->gn_in_rps > 0 && a->gn_in_rows > 0, "v3d_gemm: gn_in_table needs gn_in_rps and gn_in_rows");
+        const unsigned long long tb = (unsigned long long)a->gn_in_rows * a->K * 8ull;
+        V3D_REQUIRE(tb <= kMaxBufBytes && a->batch == 1 && !a->geglu, "v3d_gemm: gn_in_table too large / batched / GEGLU");
+        p.gn_in_bytes = (unsigned)tb;
+    }
+    *halo = 0;
+    if (a->mode == V3D_GEMM_CONV3X3) {
+        p.upshift = a->up - 1;
+        p.pad_lo = a->pad_mode ? 0 : 1;
+    }
+    static int hk = -1;
+    if (hk < 0) { const char* e = getenv("V3D_CONV_HALO"); hk = e ? atoi(e) : 1; }     // A/B knob: 0 = never, 1 = launches with gn_in_table (default), 2 = every launch of a fitting shape
+    if (a->batch == 1 && !a->geglu && (a->mode == V3D_GEMM_CONV3X3 || a->mode == V3D_GEMM_CONVT3) && ((hk == 1 && a->gn_in_table) || hk >= 2))
+        *halo = v3d_conv_halo_variant(p, a->mode);
+    return V3D_OK;
+}
+}  // namespace
+
+extern "C" int v3d_gemm_gn_in_supported(const v3d_gemm_args* a) {
+    GP p;
+    int halo = 0;
+    if (!a || !a->gn_in_table || fill_params(a, p, &halo) != V3D_OK) return 0;
+    return halo != 0;
+}
+
+extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
+    GP p;
+    int halo = 0;
+    const int frc = fill_params(a, p, &halo);
+    if (frc != V3D_OK) return frc;
+    hipStream_t st = (hipStream_t)stream;
+    if (halo) return v3d_conv_halo_launch(p, halo, stream);       // (its epilogue gathers gn_stats itself)
+    V3D_REQUIRE(!a->gn_in_table, "v3d_gemm: gn_in_table is set but this shape is not one of the LDS-haloed kernels' (v3d_gemm_gn_in_supported): "
+                                 "normalise the input with v3d_groupnorm_apply first");
+    if (p.gn_stats || a->gn_stats) {
         g_gn_in_epilogue = false;
         const int rc = run_mode(a, p, st);
         if (rc != V3D_OK || g_gn_in_epilogue) return rc;
         // the kernel that ran has no statistics epilogue (v1 / v2 tiles, split-K, ragged shapes): same result from the stand-alone kernel
-        return v3d_groupnorm_stats(a->out, a->N, nullptr, 0, a->gn_stats, a->M / a->gn_rps, a->gn_rps, 32, 1, stream);
+        return v3d_groupnorm_stats(a->out, a->N, nullptr, 0, a->gn_stats, a->gn_nslots, a->M / a->gn_rps, a->gn_rps, 32, 1, stream);
     }
     return run_mode(a, p, st);
 }

@@ -1,0 +1,521 @@
+// Shared device code of the v3d_gemm kernel family (gemm.hip) and the LDS-haloed convolution (conv.hip): launch parameters, tap / row
+// addressing, XCD-aware tile walk, the fused epilogue (bias / per-image vector / GEGLU / residuals / alpha blend, LDS-staged 16-byte row
+// stores) and the GroupNorm-statistics epilogue.  Everything but the parameter block lives in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+// Experiment switches (skip epilogue / MFMAs / DMA / stores, slot timelines) exist only in builds made with -DV3D_EXPERIMENTS
+// (tools/gemm_floor.py, tools/v3_timeline.py say how); the shipped library has no environment variable that changes results.
+#ifdef V3D_EXPERIMENTS
+#define V3D_ABL(p, bit) ((p).ablate & (bit))
+#else
+#define V3D_ABL(p, bit) (0)
+#endif
+
+struct V3dGemmParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    void* out;
+    const float* bias;
+    const float* add;
+    const bf16_t* res1;
+    const bf16_t* res2;
+    const float* coef;
+    long long M, N, K;
+    long long lda, ldw, ldo, ldr1, ldr2;
+    long long add_rpg, add_ld, coef_rpg;
+    float c_acc, c_res1, c_res2;
+    int out_fp32;
+    long long a_row0;
+    unsigned a_bytes, w_bytes;
+    int Hin, Win, Hout, Wout, stride, upshift;
+    int pad_lo;          // zero pixels before the first row / column (1, or 0 for the asymmetric right/bottom padding)
+    int T, tmin, tmax;
+    long long S;
+    long long halo_rows; // CONVT3 split-halo layout (0 = dense)
+    long long sA, sW, sO;
+    int mt, nt;  // tile counts
+    int group_m;         // tile walk: > 1 = ids run down groups of `group_m` tile rows first (L2-friendly patches), else row-major over N
+    int tap_inner;       // multi-tap modes: 1 = stage order (k outer, tap inner): the taps re-read an activation tile while it is still in L2
+    int split_n;         // > 1: split-K launch: blockIdx.y = split index = output slab (out = fp32 workspace [split][M][N], plain stores)
+    const float* ws;     // finalize kernel only: the workspace to reduce
+    int ablate;  // experiments only (env V3D_GEMM_ABLATE): 1 = no output stores, 2 = no MFMAs, 4 = no LDS-DMA loads
+    float* gn_stats;     // GroupNorm partial sums of the output [M / gn_rps][gn_nslots][32][2], stored by the <GN> epilogues (else NULL)
+    long long gn_rps;    // rows per statistics group
+    long long gn_nslots; // slots per statistics group; a writer (wave tile x statistics group) owns slot ceil(first row in group / wave-tile rows)
+    int gn_cpg;          // channels per group (N / 32)
+    // GroupNorm (+SiLU) of the INPUT applied in the operand path (conv.hip): A (and A2 behind K1 channels) hold the raw tensor
+    const bf16_t* A2;    // second channel-concatenated source (K - K1 channels, row stride lda2) or NULL
+    long long K1, lda2;
+    unsigned a2_bytes;
+    const float* gn_in;  // [stat][K][2] fp32 (scale, shift) table of v3d_groupnorm_finalize, stat = source row / gn_in_rps
+    long long gn_in_rps;
+    int gn_in_silu;
+    unsigned gn_in_bytes;   // size of the table (buffer descriptor)
+};
+
+// conv.hip: the LDS-haloed kernels (GroupNorm + SiLU in the operand path)
+int v3d_conv_halo_variant(const V3dGemmParams& p, int mode);          // 0 = not one of their shapes
+int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream);
+
+namespace {
+
+using GP = V3dGemmParams;
+
+// compile-time loop (bodies that pick between named register arrays must not wait for the late loop unroller: SROA has
+// already given up on the arrays by then and they land in scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int MODE>
+struct RowInfo {};
+
+template <>
+struct RowInfo<V3D_GEMM_LINEAR> {
+    long long src;
+    bool ok;
+    __device__ void init(const GP& p, long long m) {
+        ok = m < p.M;
+        src = m;
+    }
+    __device__ bool tap(const GP&, int, long long& s) const {
+        s = src;
+        return ok;
+    }
+};
+
+template <>
+struct RowInfo<V3D_GEMM_CONV3X3> {
+    long long base;
+    int iy0, ix0;
+    bool ok;
+    __device__ void init(const GP& p, long long m) {
+        ok = m < p.M;
+        long long hw = (long long)p.Hout * p.Wout;
+        long long img = m / hw;
+        int rem = (int)(m - img * hw);
+        int oy = rem / p.Wout;
+        int ox = rem - oy * p.Wout;
+        base = img * (long long)p.Hin * p.Win;
+        iy0 = oy * p.stride - p.pad_lo;
+        ix0 = ox * p.stride - p.pad_lo;
+    }
+    __device__ bool tap(const GP& p, int t, long long& s) const {
+        int ky = t / 3, kx = t - ky * 3;
+        int iy = iy0 + ky, ix = ix0 + kx;
+        bool v = ok && iy >= 0 && ix >= 0 && iy < (p.Hin << p.upshift) && ix < (p.Win << p.upshift);
+        s = base + (long long)(iy >> p.upshift) * p.Win + (ix >> p.upshift);
+        return v;
+    }
+};
+
+template <>
+struct RowInfo<V3D_GEMM_CONVT3> {
+    long long m_;
+    long long hoff_;   // split-halo layout only: b * S + s, the row of this (sample, position) inside a halo slab
+    int t_;
+    bool ok;
+    __device__ void init(const GP& p, long long m) {
+        ok = m < p.M;
+        m_ = m;
+        long long frame = m / p.S;
+        t_ = (int)(frame % p.T);
+        hoff_ = (frame / p.T) * p.S + (m - frame * p.S);
+    }
+    __device__ bool tap(const GP& p, int t, long long& s) const {
+        int tt = t_ + t - 1;
+        s = m_ + (long long)(t - 1) * p.S;
+        // frame sharding (halo_rows = B * S): frame -1 of every sample lives in the slab in FRONT of the local frames, frame T in
+        // the slab BEHIND them, so the +-1 frames of a sample never alias the neighbouring sample's frames and all B samples of
+        // a rank go through one launch
+        if (p.halo_rows > 0) {
+            if (tt < 0) s = hoff_ - p.halo_rows;
+            else if (tt >= p.T) s = p.M + hoff_;
+        }
+        return ok && tt >= p.tmin && tt <= p.tmax;
+    }
+};
+
+template <int MODE>
+constexpr int ntaps() {
+    return MODE == V3D_GEMM_LINEAR ? 1 : (MODE == V3D_GEMM_CONV3X3 ? 9 : 3);
+}
+
+// XCD-aware bijective remap of a 1-D grid: consecutive logical tiles share an XCD (and its L2)
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// tile id -> (tile row, tile column).  Consecutive ids run concurrently on one XCD (xcd_remap), i.e. share one 4 MiB L2: walking N fastest
+// makes 32-64 concurrent tiles of ONE tile row re-stream the whole weight matrix per row of tiles (PMC, profiles/r02a_pmc_per_launch.txt:
+// the N = 10240 GEGLU projection fetched 20x its algorithmic bytes).  group_m > 1 walks down `group_m` tile rows before moving to the next
+// tile column, so the concurrent set is a group_m x (concurrency / group_m) patch that shares both operands; bijective for any mt, nt.
+__device__ __forceinline__ void tile_coords(const GP& p, int id, int& tm, int& tn) {
+    const int gm = p.group_m >= 0 ? p.group_m : (p.mt >= 96 ? 8 : 4);     // < 0: heuristic (see the knob comment at the top)
+    if (gm <= 1 || p.nt == 1) {
+        tn = id % p.nt;
+        tm = id / p.nt;
+        return;
+    }
+    const int width = gm * p.nt;
+    const int gid = id / width;
+    const int first = gid * gm;
+    const int gsz = (p.mt - first) < gm ? (p.mt - first) : gm;
+    const int r = id - gid * width;
+    tn = r / gsz;
+    tm = first + (r - tn * gsz);
+}
+
+// ---- epilogue shared by both main loops --------------------------------------------------------------------------
+// The wave holds MF x NF fragments; per fragment a lane owns 4 consecutive n (= (lane>>4)*4 + r) of pixel m = lane&15.
+// bf16 outputs are staged through a wave-private LDS region (`stage`, >= MF*16 rows of (WNout*2 + 16) bytes) and leave as
+// 16-byte-per-lane stores covering whole row segments.  Two code paths: a branch-free FAST path for wave tiles that lie
+// completely inside the output (every predicate is wave-uniform: float4 bias / per-image vector loads, 8-byte residual
+// loads, no per-element bounds checks) and the generic path with per-element predicates for ragged M / N edges.
+// (The first version had only the generic path: 1500 VALU + 380 exec-mask branches per wave against 160 MFMAs on the
+// K = 320 GEGLU GEMM, see profiles/r01_gemm_ablation.txt.)
+// residual #1 rows of one (MF*16) x (NFO*16) wave tile as coalesced 16-byte pieces (the layout the staging buffer uses):
+// piece K of lane l is chunk c = K*64 + l -> row c / CPRO, 16-byte column chunk c % CPRO.  The v3 kernels prefetch these one
+// epilogue chunk ahead and hand them over BY VALUE (a struct / array handed over by reference went through scratch).
+template <int MF, int NF, bool GEGLU>
+struct ResGeom {
+    static constexpr int NFO = GEGLU ? NF / 2 : NF;
+    static constexpr int CPRO = NFO * 2, ROWS = MF * 16, NV = (ROWS * CPRO + 63) / 64;
+};
+template <int K, int MF, int NF, bool GEGLU>
+__device__ __forceinline__ u32x4 load_res_piece(const GP& p, long long mw0, long long nw0, int lane) {
+    using G = ResGeom<MF, NF, GEGLU>;
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if constexpr (K < G::NV) {
+        const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;
+        const int c = K * 64 + lane;
+        if ((G::ROWS * G::CPRO) % 64 == 0 || c < G::ROWS * G::CPRO)
+            r = *reinterpret_cast<const u32x4*>(p.res1 + (mw0 + c / G::CPRO) * p.ldr1 + ncol0 + (c % G::CPRO) * 8);
+    }
+    return r;
+}
+template <int K, int MF, int NF, bool GEGLU>
+__device__ __forceinline__ void res_piece_to_stage(u32x4 r, unsigned char* stage, int srow, int lane) {
+    using G = ResGeom<MF, NF, GEGLU>;
+    if constexpr (K < G::NV) {
+        const int c = K * 64 + lane;
+        if ((G::ROWS * G::CPRO) % 64 == 0 || c < G::ROWS * G::CPRO) *reinterpret_cast<u32x4*>(stage + (c / G::CPRO) * srow + (c % G::CPRO) * 16) = r;
+    }
+}
+
+// ---- GroupNorm statistics of the output, gathered where it is produced (v3 <GN> kernels) ----------------------------------------
+// Every ResBlock convolution is followed by a GroupNorm of its output (openaimodel.py:267-271,302-305 / video_model.py:42-55); the
+// stand-alone statistics kernel re-reads that tensor from HBM.  Here a wave adds up (sum, sum of squares) of the bf16-ROUNDED values it
+// stores - the numbers v3d_groupnorm_stats would read back - per channel over the rows of its tile that belong to one statistics group
+// (rows / gn_rps: an image, or the T images of a sample for the 3-D norm): in registers over the row fragments, across the 16 pixel lanes
+// with DPP row shifts, through the wave's staging region to one lane per GroupNorm group, then ONE 8-byte store per group into the writer's
+// own slot of the [stat][slot][32][2] buffer the stand-alone kernel fills (no atomics: the sums are bit-reproducible).  A writer is a wave
+// tile's run of rows inside one statistics group; wave tiles are WM-aligned row ranges, so slot = ceil(first row within the group / WM) is
+// unique per writer (the host checks WN % gn_cpg == 0: no group is shared by two wave columns, and gn_nslots >= gn_rps / WM + 2).
+template <int NF>
+struct GnAcc {
+    float s[NF][2], q[NF][2];     // per fragment column j: channel pairs (4 q + 0, 1) and (4 q + 2, 3) of the lane's 4 channels - groups hold an even
+};                                // number of channels, so a pair never straddles two of them
+template <int NF>
+__device__ __forceinline__ void gn_zero(GnAcc<NF>& a) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j) a.s[j][0] = a.s[j][1] = a.q[j][0] = a.q[j][1] = 0.f;
+}
+// one packed bf16 pair of the stored tile: sum and sum of squares by v_dot2_f32_bf16 (exact products, fp32 accumulation, no unpacking)
+typedef __bf16 gn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gn_add_pair(float& s, float& q, uint32_t w) {
+    const gn_bf16x2 v = __builtin_bit_cast(gn_bf16x2, w), ones = __builtin_bit_cast(gn_bf16x2, 0x3f803f80u);
+    s = __builtin_amdgcn_fdot2_f32_bf16(v, ones, s, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(v, v, q, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr(float v) {    // value of the lane CTRL positions below in the 16-lane row, 0 past the row start
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 | CTRL, 0xf, 0xf, true));
+}
+template <int NF>
+__device__ __forceinline__ void gn_flush(const GP& p, GnAcc<NF>& a, long long sid, long long nw0, int lane, unsigned char* stage, unsigned slot) {
+    float* sf = reinterpret_cast<float*>(stage);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        f32x4 t = {a.s[j][0], a.s[j][1], a.q[j][0], a.q[j][1]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = t[e];
+            v += dpp_row_shr<1>(v);
+            v += dpp_row_shr<2>(v);
+            v += dpp_row_shr<4>(v);
+            v += dpp_row_shr<8>(v);     // lane 15 of each row: the row's total
+            t[e] = v;
+        }
+        // 4 lanes: channel pairs of channels j * 16 + (lane >> 4) * 4 .. + 3 of the wave tile, as {s01, s23, q01, q23}
+        if ((lane & 15) == 15) lds_store16_nowait(sf + (j * 4 + (lane >> 4)) * 4, t);
+    }
+    // one lane per GroupNorm group that intersects the wave tile's channels [nw0, nw0 + NF * 16)
+    const int cpg = p.gn_cpg;
+    const int g_lo = (int)(nw0 / cpg), g_hi = (int)((nw0 + NF * 16 - 1) / cpg);
+    const int g = g_lo + lane;
+    if (g <= g_hi) {
+        const int c0 = g * cpg > (int)nw0 ? g * cpg - (int)nw0 : 0;
+        const int c1 = (g + 1) * cpg - (int)nw0 < NF * 16 ? (g + 1) * cpg - (int)nw0 : NF * 16;
+        float sa = 0.f, sb = 0.f;
+        for (int cp = c0 >> 1; cp < (c1 >> 1); ++cp) {            // channel pair cp = channels 2 cp, 2 cp + 1 of the tile
+            const float* e = sf + (cp >> 1) * 4 + (cp & 1);
+            sa += e[0];
+            sb += e[2];
+        }
+        float* dst = p.gn_stats + ((sid * p.gn_nslots + slot) * 32 + g) * 2;
+        *reinterpret_cast<float2*>(dst) = make_float2(sa, sb);
+    }
+    gn_zero(a);
+}
+
+template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false, int SPAD = 16, bool GN = false>
+__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
+                                         unsigned char* stage, u32x4 pre0, u32x4 pre1, u32x4 pre2, bool res_pre,
+                                         const float4 (&bias_pre)[NF], bool has_bias_pre, GnAcc<GN ? NF : 1>* gn = nullptr) {
+    if V3D_ABL(p, 1) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sum == 123.456f) reinterpret_cast<float*>(p.out)[0] = sum;   // keeps the accumulators live
+        return;
+    }
+    const long long Nout = GEGLU ? p.N / 2 : p.N;
+    constexpr int NFO = GEGLU ? NF / 2 : NF;          // output fragments per wave-tile row
+    constexpr int SROW = NFO * 32 + SPAD;             // staging row stride in bytes (16 B pad unless LDS is too tight)
+    const long long ncol0 = GEGLU ? ((nw0 >> 5) * 16) : nw0;   // first output column of this wave tile
+    const bool staged = CAN_STAGE && !p.out_fp32 && (p.ldo % 8 == 0) && (ncol0 % 8 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.out) + (size_t)z * p.sO * 2) % 16 == 0);
+    const bool vec_ok = (p.ldo % 4 == 0) && (!p.res1 || p.ldr1 % 4 == 0) && (!p.res2 || p.ldr2 % 4 == 0);
+    const bool fast = (mw0 + MF * 16 <= p.M) && (nw0 + NF * 16 <= p.N) && vec_ok && (staged || p.out_fp32) &&
+                      (!p.add || ((reinterpret_cast<uintptr_t>(p.add) % 16 == 0) && (p.add_ld % 4 == 0))) &&
+                      (!p.res1 || reinterpret_cast<uintptr_t>(p.res1) % 8 == 0) && (!p.res2 || reinterpret_cast<uintptr_t>(p.res2) % 8 == 0);
+    const int fr = lane & 15, fq = (lane >> 4) * 4;
+    if (FAST_ONLY && (mw0 >= p.M || nw0 >= p.N)) return;   // wave tile completely outside a partial edge tile
+    if (FAST_ONLY || fast) {   // FAST_ONLY: the host has checked the fast-path conditions for every wave tile (v3 kernels)
+        const int nb = (int)nw0 + fq;                  // this lane's first packed weight row (tile-relative math in 32 bit)
+        constexpr int CPRO = NFO * 2;                  // 16-byte chunks per staged row
+        constexpr int ROWS = MF * 16;
+        constexpr bool WHOLE = (ROWS * CPRO) % 64 == 0;   // else the last wave-wide copy of the staged tile is partial
+        // residual #1 comes in through the staging buffer: coalesced 16-byte row loads -> LDS, then each lane picks its 8 bytes in
+        // MFMA layout (the direct 8-byte-per-lane residual loads touched 16 rows per instruction: 129 us vs 70 us for the
+        // attention out-projection at 64x64, profiles/r01d_op_times_unet_eval.txt)
+        const bool res1_lds = CAN_STAGE && p.res1 && !p.out_fp32 && (p.ldr1 % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res1) % 16 == 0);
+        if (CAN_STAGE && res1_lds) {
+            if (res_pre) {   // (only offered by callers whose wave-tile chunk has at most 3 pieces per lane)
+                res_piece_to_stage<0, MF, NF, GEGLU>(pre0, stage, SROW, lane);
+                res_piece_to_stage<1, MF, NF, GEGLU>(pre1, stage, SROW, lane);
+                res_piece_to_stage<2, MF, NF, GEGLU>(pre2, stage, SROW, lane);
+            } else {
+                const bf16_t* rz = p.res1 + mw0 * p.ldr1 + ncol0;
+                uint4 rv[(ROWS * CPRO + 63) / 64];
+#pragma unroll
+                for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                    const int c = c0 + lane;
+                    if (WHOLE || c < ROWS * CPRO) rv[c0 / 64] = *reinterpret_cast<const uint4*>(rz + (long long)(c / CPRO) * p.ldr1 + (c % CPRO) * 8);
+                }
+#pragma unroll
+                for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                    const int c = c0 + lane;
+                    if (WHOLE || c < ROWS * CPRO) *reinterpret_cast<uint4*>(stage + (c / CPRO) * SROW + (c % CPRO) * 16) = rv[c0 / 64];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const bool scale_acc = p.coef != nullptr || p.c_acc != 1.0f;   // wave-uniform
+        float4 bv[NF];
+        if (has_bias_pre) {   // the caller loaded this wave tile's bias columns once for all of its row chunks
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bv[j] = bias_pre[j];
+        } else if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + nb + j * 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const long long m = mw0 + i * 16 + fr;
+            float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
+            if (p.coef) {
+                const float* cf = p.coef + (m / p.coef_rpg) * 3;
+                ca = cf[0]; c1 = cf[1]; c2 = cf[2];
+            }
+            const float* addv = p.add ? p.add + (m / p.add_rpg) * p.add_ld + nb : nullptr;
+            const bf16_t* r1 = (p.res1 && !res1_lds) ? p.res1 + m * p.ldr1 + (int)ncol0 + fq : nullptr;
+            const bf16_t* r2 = p.res2 ? p.res2 + m * p.ldr2 + (int)ncol0 + fq : nullptr;
+            float* of = p.out_fp32 ? reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + (int)ncol0 + fq : nullptr;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                if (GEGLU && (j & 1)) continue;
+                float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+                if (addv) {
+                    const float4 a = *reinterpret_cast<const float4*>(addv + j * 16);
+                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                }
+                if (GEGLU) {
+                    constexpr int dummy = 0;
+                    const int jg = (j + 1 < NF) ? j + 1 : j;
+                    float g[4] = {acc[i][jg][0] + bv[jg].x, acc[i][jg][1] + bv[jg].y, acc[i][jg][2] + bv[jg].z, acc[i][jg][3] + bv[jg].w};
+                    if (addv) {
+                        const float4 a = *reinterpret_cast<const float4*>(addv + jg * 16);
+                        g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = V3D_ABL(p, 16) ? v[r] * g[r] : geglu_mul(v[r], g[r]);
+                    (void)dummy;
+                }
+                const int jo = GEGLU ? (j >> 1) : j;
+                float o[4] = {v[0], v[1], v[2], v[3]};
+                if (scale_acc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] *= ca;
+                }
+                if (CAN_STAGE && res1_lds) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2);
+                    o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
+                } else if (r1) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(r1 + jo * 16);
+                    o[0] += c1 * bflo(rr.x); o[1] += c1 * bfhi(rr.x); o[2] += c1 * bflo(rr.y); o[3] += c1 * bfhi(rr.y);
+                }
+                if (r2) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(r2 + jo * 16);
+                    o[0] += c2 * bflo(rr.x); o[1] += c2 * bfhi(rr.x); o[2] += c2 * bflo(rr.y); o[3] += c2 * bfhi(rr.y);
+                }
+                if (of) {
+                    *reinterpret_cast<float4*>(of + jo * 16) = make_float4(o[0], o[1], o[2], o[3]);
+                } else if (CAN_STAGE) {
+                    const uint32_t w0 = pack2bf(o[0], o[1]), w1 = pack2bf(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(stage + (i * 16 + fr) * SROW + jo * 32 + fq * 2) = make_uint2(w0, w1);
+                    if constexpr (GN) {
+                        gn_add_pair(gn->s[j][0], gn->q[j][0], w0);
+                        gn_add_pair(gn->s[j][1], gn->q[j][1], w1);
+                    }
+                }
+            }
+        }
+        if (CAN_STAGE && !p.out_fp32) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bf16_t* outz = reinterpret_cast<bf16_t*>(p.out) + z * p.sO + mw0 * p.ldo + ncol0;
+#pragma unroll
+            for (int c0 = 0; c0 < ROWS * CPRO; c0 += 64) {
+                const int c = c0 + lane;
+                const int row = c / CPRO, ch = c % CPRO;
+                if ((WHOLE || c < ROWS * CPRO) && !V3D_ABL(p, 32)) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
+            }
+        }
+        return;
+    }
+    if (FAST_ONLY) return;
+    // ---------------- generic path (ragged edges) ----------------
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const long long m = mw0 + i * 16 + fr;
+        if (m >= p.M) continue;
+        float ca = p.c_acc, c1 = p.c_res1, c2 = p.c_res2;
+        if (p.coef) {
+            const float* cf = p.coef + (m / p.coef_rpg) * 3;
+            ca = cf[0];
+            c1 = cf[1];
+            c2 = cf[2];
+        }
+        const float* addv = p.add ? p.add + (m / p.add_rpg) * p.add_ld : nullptr;
+#pragma unroll
+        for (int j = 0; j < NF; j += 1) {
+            if (GEGLU && (j & 1)) continue;  // gate fragments are consumed with their value fragment
+            const long long np = nw0 + j * 16 + fq;  // packed weight-row index
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];
+                if (np + r < p.N) {
+                    if (p.bias) v[r] += p.bias[np + r];
+                    if (addv) v[r] += addv[np + r];
+                }
+            }
+            long long col = np;
+            if (GEGLU) {
+                const int jg = (j + 1 < NF) ? j + 1 : j;
+                const long long ng = np + 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float g = acc[i][jg][r];
+                    if (ng + r < p.N) {
+                        if (p.bias) g += p.bias[ng + r];
+                        if (addv) g += addv[ng + r];
+                    }
+                    v[r] = v[r] * gelu_erf_f(g);
+                }
+                col = (np >> 5) * 16 + (np & 15);
+            }
+            if (col >= Nout) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (col + r < Nout) {
+                    float o = ca * v[r];
+                    if (p.res1) o += c1 * bf2f(p.res1[m * p.ldr1 + col + r]);
+                    if (p.res2) o += c2 * bf2f(p.res2[m * p.ldr2 + col + r]);
+                    if (p.out_fp32)
+                        (reinterpret_cast<float*>(p.out) + z * p.sO + m * p.ldo + col)[r] = o;
+                    else
+                        (reinterpret_cast<bf16_t*>(p.out) + z * p.sO + m * p.ldo + col)[r] = f2bf(o);
+                }
+            }
+        }
+    }
+}
+
+template <int MF, int NF, bool GEGLU, bool CAN_STAGE, bool FAST_ONLY = false>
+__device__ __forceinline__ void epilogue(const GP& p, f32x4 (&acc)[MF][NF], long long mw0, long long nw0, long long z, int lane,
+                                         unsigned char* stage) {
+    const u32x4 none = {0u, 0u, 0u, 0u};
+    float4 nob[NF];
+    epilogue<MF, NF, GEGLU, CAN_STAGE, FAST_ONLY>(p, acc, mw0, nw0, z, lane, stage, none, none, none, false, nob, false);
+}
+
+
+// retire the finished tile of a v3 wave in chunks of EMF row fragments; residual rows come in one chunk ahead of their use
+// (a per-chunk load -> LDS -> use chain exposed the full load latency 8 times per tile: the [bar] out-projections ran
+// 15-50 % slower than on v2)
+template <int C, int NCH, int EMF, int NF, bool GEGLU, int SPAD, bool GN>
+__device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH * EMF][NF], long long mw0, long long nw0, int lane, unsigned char* estage,
+                                                 u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre, const float4 (&bv)[NF], GnAcc<GN ? NF : 1>& gn,
+                                                 long long sid0, unsigned rem0) {
+    static_assert(ResGeom<EMF, NF, GEGLU>::NV <= 3, "v3 epilogue chunk: at most 3 residual pieces per lane");
+    if constexpr (C < NCH) {
+        u32x4 n0 = c0, n1 = c1, n2 = c2;
+        if constexpr (C + 1 < NCH) {
+            if (res_pre) {
+                n0 = load_res_piece<0, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
+                n1 = load_res_piece<1, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
+                n2 = load_res_piece<2, EMF, NF, GEGLU>(p, mw0 + (C + 1) * EMF * 16, nw0, lane);
+            }
+        }
+        epilogue<EMF, NF, GEGLU, true, true, SPAD, GN>(p, *reinterpret_cast<f32x4(*)[EMF][NF]>(&acc[C * EMF]), mw0 + C * EMF * 16, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true, &gn);
+        if constexpr (GN) {
+            // rows of this chunk belong to statistics group sid0 + (rem0 + C * 16) / gn_rps; hand the sums over when the next chunk
+            // starts another group (a tile may straddle images: 4096 rows per image, 96 per wave tile) or the tile ends
+            static_assert(EMF == 1, "GN epilogue: one row fragment per chunk");
+            const unsigned rps = (unsigned)p.gn_rps;
+            const unsigned here = (rem0 + C * 16) / rps, next = (rem0 + (C + 1) * 16) / rps;
+            // the run of rows that ends here started at the wave tile's first row (first group of the tile) or at the group's first row
+            const unsigned off = here == rem0 / rps ? rem0 - here * rps : 0u;
+            if (C + 1 == NCH || next != here) gn_flush<NF>(p, gn, sid0 + here, nw0, lane, estage, (off + NCH * 16 - 1) / (NCH * 16));
+        }
+        v3_retire_chunks<C + 1, NCH, EMF, NF, GEGLU, SPAD, GN>(p, acc, mw0, nw0, lane, estage, n0, n1, n2, res_pre, bv, gn, sid0, rem0);
+    }
+}
+
+}  // namespace

@@ -6,7 +6,6 @@
 
 namespace {
 
-constexpr int SLOTS = V3D_GN_SLOTS;   // partial-sum slots per statistics group (spreads the fp32 atomics)
 constexpr int NVMAX = 2;       // vector columns per thread -> supports C <= 2*256*8 = 4096
 constexpr int CMAX = 4096;
 
@@ -36,28 +35,28 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
     f[4] = bflo(u.z); f[5] = bfhi(u.z); f[6] = bflo(u.w); f[7] = bfhi(u.w);
 }
 
-// grid (chunks, n_img); block 256.  Each block reduces rows [chunk*rpb, (chunk+1)*rpb) of one image.
+// grid (chunks, n_img); block 256.  Each block reduces rows [chunk*rpb, (chunk+1)*rpb) of one image and stores its (sum, sumsq) per
+// group into ITS OWN slot of the statistics buffer: slot = (img % imgs_per_stat) * chunks + chunk - plain stores, no atomics anywhere,
+// so the statistics (and with them every GroupNorm output) are bit-reproducible run to run.  (Rounds 1-2 met in fp32 atomics: LDS atomics
+// across the rows of a block, global atomics across blocks; two identical evaluations differed by 1-2e-2 after 50 layers.)
 // NV (vector columns per thread) is a template parameter and the per-channel LDS partials are sized by C (dynamic shared
 // memory): the first version carried the dead second column through every load / fma and declared 32 KiB of LDS, which
 // capped a CU at 5 blocks - 56 us for the 94 MB 64x64 level where the read+write gn_apply takes 36 us.
 template <int NV, int UR>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x1, long long C1,
                                                        const bf16_t* __restrict__ x2, long long C2,
-                                                       float* __restrict__ stats, long long S, int groups,
+                                                       float* __restrict__ stats, long long nslots, long long S, int groups,
                                                        long long imgs_per_stat, long long rpb) {
-    extern __shared__ float gn_sh[];   // [2][C]: per-channel sum, sum of squares
+    extern __shared__ float gn_sh[];   // [2][RPP][C]: per (row lane, channel) sum, sum of squares
     const long long C = C1 + C2;
-    float* sh_s = gn_sh;
-    float* sh_q = gn_sh + C;
     const GNGeom g = gn_geom(C);
+    float* sh_s = gn_sh;
+    float* sh_q = gn_sh + (long long)g.RPP * C;
     const int tid = threadIdx.x;
     const long long img = blockIdx.y;
     const long long r_begin = (long long)blockIdx.x * rpb;
     long long r_end = r_begin + rpb;
     if (r_end > S) r_end = S;
-
-    for (int c = tid; c < 2 * C; c += 256) gn_sh[c] = 0.f;
-    __syncthreads();
 
     const int trow = tid / g.TPR;
     const int tcol = tid - trow * g.TPR;
@@ -100,8 +99,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
             if (v < g.VC) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    atomicAdd(&sh_s[v * 8 + e], s[j][e]);
-                    atomicAdd(&sh_q[v * 8 + e], q[j][e]);
+                    sh_s[(long long)trow * C + v * 8 + e] = s[j][e];
+                    sh_q[(long long)trow * C + v * 8 + e] = q[j][e];
                 }
             }
         }
@@ -110,26 +109,75 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     const int cpg = (int)(C / groups);
     if (tid < groups) {
         float a = 0.f, b = 0.f;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-            a += sh_s[c];
-            b += sh_q[c];
+        for (int r = 0; r < g.RPP; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {      // fixed order: the result does not depend on scheduling
+                a += sh_s[(long long)r * C + c];
+                b += sh_q[(long long)r * C + c];
+            }
+        const long long slot = (img % imgs_per_stat) * gridDim.x + blockIdx.x;
+        float* dst = stats + (((img / imgs_per_stat) * nslots + slot) * groups + tid) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+// One block per statistics group: the slots' partial sums are added up in a FIXED order in fp64 (4 slot lanes per (group, component), then
+// the 4 lanes in order), mean / variance / rstd in fp64 (E[x^2] - E[x]^2 cancels in fp64, not fp32: inputs with |mean| >> std keep their
+// variance), and the per-(statistics group, channel) affine of the normalisation is written as a table
+//   table[stat][c] = (scale, shift) = (gamma[c] rstd[g],  beta[c] - mean[g] gamma[c] rstd[g])          y = x * scale + shift
+// which is all a consumer needs: v3d_groupnorm_apply, and the convolutions that normalise their input tile on its way into LDS
+// (v3d_gemm gn_in_table).  `sums` [n_stat][groups][2] fp64 is the frame-sharded runtime's hand-off: written when the slots are given,
+// read (after the all-reduce over ranks) when they are not.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, long long nslots, double* __restrict__ sums, int groups,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, long long C,
+                                                          double inv_count, float eps, float* __restrict__ table) {
+    __shared__ double part[4][512];
+    __shared__ float ms[512];          // [group][2]: mean, rstd
+    const int tid = threadIdx.x;
+    const long long st = blockIdx.x;
+    const int npair = groups * 2;      // <= 512
+    if (stats) {
+        for (int p0 = 0; p0 < npair; p0 += 64) {
+            const int pr = p0 + (tid & 63), sl = tid >> 6;
+            double a = 0.0;
+            if (pr < npair) {
+                const float* sp = stats + (st * nslots) * npair + pr;
+                for (long long k = sl; k < nslots; k += 4) a += (double)sp[k * npair];
+            }
+            if (pr < npair) part[sl][pr] = a;
         }
-        // slot = row-chunk index modulo SLOTS: a 3-D GroupNorm reduces T x chunks blocks into the same group, and
-        // ~1000 same-address atomics serialised in the first version (profiles/r01b_kernel_stats_v2.txt)
-        const int slot = (int)((blockIdx.x + img * 7) % SLOTS);
-        float* dst = stats + (((img / imgs_per_stat) * SLOTS + slot) * groups + tid) * 2;
-        atomicAdd(dst, a);
-        atomicAdd(dst + 1, b);
+        __syncthreads();
+        for (int pr = tid; pr < npair; pr += 256) {
+            const double a = ((part[0][pr] + part[1][pr]) + part[2][pr]) + part[3][pr];
+            part[0][pr] = a;
+            if (sums) sums[st * npair + pr] = a;
+        }
+    } else {
+        for (int pr = tid; pr < npair; pr += 256) part[0][pr] = sums[st * npair + pr];
+    }
+    __syncthreads();
+    if (!table) return;
+    for (int gidx = tid; gidx < groups; gidx += 256) {
+        const double mean = part[0][gidx * 2] * inv_count;
+        double var = part[0][gidx * 2 + 1] * inv_count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        ms[gidx * 2] = (float)mean;
+        ms[gidx * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = (int)(C / groups);
+    for (long long c = tid; c < C; c += 256) {
+        const int gidx = (int)(c / cpg);
+        const float sc = gamma[c] * ms[gidx * 2 + 1];
+        *reinterpret_cast<float2*>(table + (st * C + c) * 2) = make_float2(sc, beta[c] - ms[gidx * 2] * sc);
     }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x1, long long C1,
                                                        const bf16_t* __restrict__ x2, long long C2,
-                                                       const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       bf16_t* __restrict__ out, long long S, int groups,
-                                                       long long imgs_per_stat, float inv_count, float eps, int silu,
-                                                       long long rpb) {
+                                                       const float* __restrict__ table,
+                                                       bf16_t* __restrict__ out, long long S,
+                                                       long long imgs_per_stat, int silu, long long rpb) {
     const long long C = C1 + C2;
     const GNGeom g = gn_geom(C);
     const int tid = threadIdx.x;
@@ -139,22 +187,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     if (r_end > S) r_end = S;
     const int trow = tid / g.TPR;
     const int tcol = tid - trow * g.TPR;
-    const int cpg = (int)(C / groups);
-    // combine the SLOTS partial sums of this image's statistics group once per block
-    __shared__ float st[2 * 256];
-    if (tid < groups) {
-        const float* sp = stats + ((img / imgs_per_stat) * SLOTS * groups + tid) * 2;
-        float a = 0.f, b = 0.f;
-#pragma unroll 8
-        for (int sl = 0; sl < SLOTS; ++sl) {
-            a += sp[sl * groups * 2];
-            b += sp[sl * groups * 2 + 1];
-        }
-        st[tid * 2] = a;
-        st[tid * 2 + 1] = b;
-    }
-    __syncthreads();
     if (trow >= g.RPP) return;
+    const float* tb = table + (img / imgs_per_stat) * C * 2;
 
     float sc[NVMAX][8], sf[NVMAX][8];
 #pragma unroll
@@ -162,16 +196,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         const int v = tcol + j * g.TPR;
         if (j < g.NV && v < g.VC) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = v * 8 + e;
-                const int grp = c / cpg;
-                const float mean = st[grp * 2] * inv_count;
-                float var = st[grp * 2 + 1] * inv_count - mean * mean;
-                var = var < 0.f ? 0.f : var;
-                const float rstd = rsqrtf(var + eps);
-                const float ga = gamma[c] * rstd;
-                sc[j][e] = ga;
-                sf[j][e] = beta[c] - mean * ga;
+            for (int e = 0; e < 8; e += 2) {
+                const float4 t = *reinterpret_cast<const float4*>(tb + (v * 8 + e) * 2);
+                sc[j][e] = t.x; sf[j][e] = t.y; sc[j][e + 1] = t.z; sf[j][e + 1] = t.w;
             }
         }
     }
@@ -345,11 +372,13 @@ int gn_check(const char* who, const void* x1, long long C1, const void* x2, long
 
 }  // namespace
 
-extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats,
+extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots,
                                    int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, v3d_stream_t stream) {
     int rc = gn_check("v3d_groupnorm_stats", x1, C1, x2, C2, n_img, S, groups);
     if (rc) return rc;
     V3D_REQUIRE(stats != nullptr && imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_stats: bad stats/imgs_per_stat");
+    V3D_REQUIRE(nslots >= imgs_per_stat, "v3d_groupnorm_stats: nslots (%lld) must be >= imgs_per_stat (%lld): one slot per block",
+                (long long)nslots, (long long)imgs_per_stat);
     const GNGeom g = gn_geom(C1 + C2);
     long long chunks, rpb;
     static long long target = -1;
@@ -357,36 +386,56 @@ extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, i
         const char* e = getenv("V3D_GN_BLOCKS");   // tuning knob (tools/gn_bench.py)
         target = e ? atoll(e) : 0;
     }
-    // few, long blocks: every block ends in 64 fp32 global atomics and those (not the reads) set the time once there are
-    // more than a few hundred blocks (tools/gn_bench.py: 64x64 level 23 / 26 / 33 / 52 / 94 us at 256 / 512 / 1024 / 2048 /
-    // 4096 blocks); very large inputs (VAE, > 256 MB) want ~3 blocks per CU to keep HBM busy
+    // few, long blocks (rounds 1-2: every block ended in 64 global atomics; now one 8-byte store per group, but ~1 block per CU still
+    // reads at the HBM rate); very large inputs (VAE, > 256 MB) want ~3 blocks per CU to keep HBM busy
     const long long bytes = n_img * S * (C1 + C2) * 2;
     gn_grid(n_img, S, g, chunks, rpb, target > 0 ? target : (bytes > (256ll << 20) ? 768 : 256));
-    const size_t shmem = (size_t)(C1 + C2) * 2 * sizeof(float);
+    if (chunks * imgs_per_stat > nslots) {       // every block of a statistics group needs its own slot
+        chunks = nslots / imgs_per_stat;
+        rpb = (S + chunks - 1) / chunks;
+        chunks = (S + rpb - 1) / rpb;
+    }
+    const size_t shmem = (size_t)(C1 + C2) * 2 * g.RPP * sizeof(float);
+    V3D_REQUIRE(shmem <= 64 * 1024, "v3d_groupnorm_stats: C=%lld needs %zu B of LDS", (long long)(C1 + C2), shmem);
     const dim3 grid((unsigned)chunks, (unsigned)n_img);
     if (g.NV == 1)
         hipLaunchKernelGGL((gn_stats_kernel<1, 8>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
-                           (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups, (long long)imgs_per_stat, rpb);
+                           (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb);
     else
         hipLaunchKernelGGL((gn_stats_kernel<2, 4>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
-                           (const bf16_t*)x2, (long long)C2, stats, (long long)S, groups, (long long)imgs_per_stat, rpb);
+                           (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb);
     return v3d_check_launch("v3d_groupnorm_stats");
 }
 
-extern "C" int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* stats,
-                                   const float* gamma, const float* beta, void* out, int64_t n_img, int64_t S,
-                                   int32_t groups, int64_t imgs_per_stat, double count, float eps, int32_t silu,
-                                   v3d_stream_t stream) {
-    int rc = gn_check("v3d_groupnorm_apply", x1, C1, x2, C2, n_img, S, groups);
+extern "C" int v3d_groupnorm_finalize(const float* stats, int64_t nslots, double* sums, int64_t n_stat, int32_t groups,
+                                      const float* gamma, const float* beta, int64_t C, double count, float eps, float* table,
+                                      v3d_stream_t stream) {
+    V3D_REQUIRE(stats || sums, "v3d_groupnorm_finalize: neither slot statistics nor reduced sums given");
+    V3D_REQUIRE(!stats || nslots > 0, "v3d_groupnorm_finalize: nslots must be > 0");
+    V3D_REQUIRE(n_stat > 0 && n_stat < (1ll << 31) && groups > 0 && groups <= 256, "v3d_groupnorm_finalize: bad n_stat / groups");
+    V3D_REQUIRE(table || (stats && sums), "v3d_groupnorm_finalize: nothing to write");
+    if (table) {
+        V3D_REQUIRE(gamma && beta && C > 0 && C % groups == 0 && count > 0, "v3d_groupnorm_finalize: table needs gamma, beta, C %% groups == 0, count > 0");
+        V3D_REQUIRE(((uintptr_t)table & 7) == 0, "v3d_groupnorm_finalize: table must be 8-byte aligned");
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)n_stat), dim3(256), 0, (hipStream_t)stream, stats, (long long)nslots, sums, groups, gamma,
+                       beta, (long long)C, count > 0 ? 1.0 / count : 0.0, eps, table);
+    return v3d_check_launch("v3d_groupnorm_finalize");
+}
+
+extern "C" int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* table, void* out,
+                                   int64_t n_img, int64_t S, int64_t imgs_per_stat, int32_t silu, v3d_stream_t stream) {
+    int rc = gn_check("v3d_groupnorm_apply", x1, C1, x2, C2, n_img, S, 1);
     if (rc) return rc;
-    V3D_REQUIRE(stats && gamma && beta && out, "v3d_groupnorm_apply: null pointer");
-    V3D_REQUIRE(imgs_per_stat > 0 && n_img % imgs_per_stat == 0 && count > 0, "v3d_groupnorm_apply: bad imgs_per_stat/count");
+    V3D_REQUIRE(table && out, "v3d_groupnorm_apply: null pointer");
+    V3D_REQUIRE(((uintptr_t)table & 15) == 0, "v3d_groupnorm_apply: table must be 16-byte aligned");
+    V3D_REQUIRE(imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_apply: bad imgs_per_stat");
     const GNGeom g = gn_geom(C1 + C2);
     long long chunks, rpb;
     gn_grid(n_img, S, g, chunks, rpb);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)chunks, (unsigned)n_img), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x1, (long long)C1, (const bf16_t*)x2, (long long)C2, stats, gamma, beta,
-                       (bf16_t*)out, (long long)S, groups, (long long)imgs_per_stat, (float)(1.0 / count), eps, silu, rpb);
+                       (const bf16_t*)x1, (long long)C1, (const bf16_t*)x2, (long long)C2, table,
+                       (bf16_t*)out, (long long)S, (long long)imgs_per_stat, silu, rpb);
     return v3d_check_launch("v3d_groupnorm_apply");
 }
 

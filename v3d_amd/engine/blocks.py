@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from ..ops import OpsBase
+from ..ops import GEMM_CONV3X3, GEMM_CONVT3, GemmCall, OpsBase
 from .packing import ResPack
 
 
@@ -49,12 +49,35 @@ class Env:
 _GN_EPILOGUE = int(os.environ.get("V3D_GN_EPILOGUE", "1") or 0)
 
 
-def _gn_producer(ops, n_stat, rps, cout, device, groups=32, level=1):
+def _gn_producer(ops, n_stat, rps, cout, device, groups=32, level=1, imgs_per_stat=1):
     """(stats buffer, GemmCall keywords) for a GEMM whose [M, cout] output feeds a 32-group GroupNorm with `rps` rows per statistics group."""
     if _GN_EPILOGUE < level or cout % (2 * groups) or rps % 16:
         return None, {}
-    st = ops.gn_stats_buffer(n_stat, device, groups)
+    st = ops.gn_stats_buffer(n_stat, device, groups, rps=rps, imgs_per_stat=imgs_per_stat)
     return st, dict(gn_stats=st, gn_rps=rps, gn_cpg=cout // groups)
+
+
+# GroupNorm + SiLU in the operand path of the convolution that consumes it (v3d_gemm gn_in_table: the LDS-haloed kernels of conv.hip
+# normalise their input tile on its way into LDS).  V3D_CONV_GN=0 restores "v3d_groupnorm_apply, then the convolution" everywhere (A/B knob).
+_CONV_GN = os.environ.get("V3D_CONV_GN", "1") not in ("", "0")
+
+
+def conv3x3_gn(ops, x1, x2, norm, w, bias, g: "Geo", *, stats=None, **epi):
+    """conv3x3(SiLU(GroupNorm(x1 | x2))): openaimodel.py:267-271 (in_layers) / 302-314 (out_layers), 2-D norm (one statistics group per image)."""
+    ga, be, eps = norm
+    n, S = g.n, g.S
+    table = ops.groupnorm_table(x1, x2, ga, be, n, S, eps=eps, stats=stats)
+    N = w.shape[-2]
+    K = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+    if _CONV_GN:
+        out = ops.empty((n * S, N), ops.act_dtype, x1.device)
+        call = GemmCall(A=x1, A2=x2, W=w, out=out, M=n * S, N=N, K=K, bias=bias, mode=GEMM_CONV3X3, Hin=g.H, Win=g.W, Hout=g.H, Wout=g.W,
+                        gn_in=table, gn_in_rps=S, gn_in_silu=True, **epi)
+        if ops.gemm_gn_in_supported(call):
+            ops.gemm(call)
+            return out
+    h = ops.groupnorm(x1, x2, ga, be, n, S, eps=eps, silu=True, table=table)
+    return ops.conv3x3(h, w, bias, n, g.H, g.W, **epi)
 
 
 def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[torch.Tensor], *, eps_override=None, out_stats_imgs=0):
@@ -63,16 +86,12 @@ def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[tor
     groups of k images (the 3-D norm of the time_stack that follows), gathered by the last convolution: (xs, stats)."""
     ops = env.ops
     S = g.S
-    ga, be, eps = p.gn1
-    h = ops.groupnorm(x1, x2, ga, be, g.n, S, eps=eps, silu=True)
     epi = {}
     if p.emb_off >= 0:
         epi = dict(add=env.emb_all[:, p.emb_off:], add_rpg=S, add_ld=env.emb_all.stride(0))
     cout = p.w1.shape[-2]
     st2, gkw = _gn_producer(ops, g.n, S, cout, x1.device)
-    h = ops.conv3x3(h, p.w1, p.b1, g.n, g.H, g.W, **epi, **gkw)
-    ga, be, eps = p.gn2
-    h = ops.groupnorm(h, None, ga, be, g.n, S, eps=eps, silu=True, stats=st2)
+    h = conv3x3_gn(ops, x1, x2, p.gn1, p.w1, p.b1, g, **epi, **gkw)
     if p.skip_w is None:
         assert x2 is None
         skip = x1
@@ -84,9 +103,26 @@ def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[tor
             skip = ops.linear(x1, p.skip_w[:, :c1], p.skip_b)
             skip = ops.linear(x2, p.skip_w[:, c1:], None, res1=skip)
     if not out_stats_imgs:
-        return ops.conv3x3(h, p.w2, p.b2, g.n, g.H, g.W, res1=skip)
-    st, gkw = _gn_producer(ops, g.n // out_stats_imgs, out_stats_imgs * S, p.w2.shape[-2], x1.device)
-    return ops.conv3x3(h, p.w2, p.b2, g.n, g.H, g.W, res1=skip, **gkw), st
+        return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip)
+    st, gkw = _gn_producer(ops, g.n // out_stats_imgs, out_stats_imgs * S, p.w2.shape[-2], x1.device, imgs_per_stat=out_stats_imgs)
+    return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip, **gkw), st
+
+
+def convt3_gn(ops, x, norm, w, bias, g: "Geo", *, stats=None, **epi):
+    """conv_t(SiLU(GroupNorm3d(x))) of the time_stack (video_model.py:42-55): 3-D norm (one statistics group per sample), (3,1,1) convolution."""
+    ga, be, eps = norm
+    n, S, T = g.n, g.S, g.T
+    table = ops.groupnorm_table(x, None, ga, be, n, S, eps=eps, imgs_per_stat=T, stats=stats)
+    N, K = w.shape[-2], x.shape[-1]
+    if _CONV_GN:
+        out = ops.empty((n * S, N), ops.act_dtype, x.device)
+        call = GemmCall(A=x, W=w, out=out, M=n * S, N=N, K=K, bias=bias, mode=GEMM_CONVT3, T=T, S=S, tmin=0, tmax=T - 1,
+                        gn_in=table, gn_in_rps=T * S, gn_in_silu=True, **epi)
+        if ops.gemm_gn_in_supported(call):
+            ops.gemm(call)
+            return out
+    h = ops.groupnorm(x, None, ga, be, n, S, eps=eps, silu=True, imgs_per_stat=T, table=table)
+    return ops.convt3(h, w, bias, T, S, **epi)
 
 
 def res_temporal(env: Env, g: Geo, p: ResPack, xs: torch.Tensor, *, coef=None, c_acc=1.0, xs_stats=None):
@@ -95,32 +131,29 @@ def res_temporal(env: Env, g: Geo, p: ResPack, xs: torch.Tensor, *, coef=None, c
     ops = env.ops
     S, T = g.S, g.T
     sh = env.shard
-    gn_kw = dict(imgs_per_stat=T)
     C = xs.shape[-1]
-    if sh is not None:
-        gn_kw.update(stats_hook=sh.allreduce_stats, count_imgs=sh.T_global)
-    # frame-sharded: GroupNorm writes the local frames straight into the middle of the split-halo buffer the 3-tap GEMM reads
-    buf, mid = sh.halo_buffer(g.B, S, C, ops.act_dtype, xs.device) if sh is not None else (None, None)
+    epi1 = {}
+    if p.t_emb_off >= 0:
+        epi1 = dict(add=env.emb_all[:, p.t_emb_off:], add_rpg=S, add_ld=env.emb_all.stride(0))
+    epi2 = dict(res1=xs)
+    if coef is not None:
+        epi2.update(coef=coef, coef_rpg=S)
+    else:
+        epi2.update(c_acc=c_acc, c_res1=1.0)
+    st2, gkw = _gn_producer(ops, g.n // T, T * S, p.t_w1.shape[-2], xs.device, level=2, imgs_per_stat=T)
+    if sh is None:
+        h = convt3_gn(ops, xs, p.t_gn1, p.t_w1, p.t_b1, g, stats=xs_stats, **epi1, **gkw)
+        return convt3_gn(ops, h, p.t_gn2, p.t_w2, p.t_b2, g, stats=st2, **epi2)
+    # frame-sharded: the statistics are all-reduced over ranks, GroupNorm writes the local frames straight into the middle of the split-halo
+    # buffer the 3-tap GEMM reads, the +-1 frames come from the neighbours
+    gn_kw = dict(imgs_per_stat=T, stats_hook=sh.allreduce_stats, count_imgs=sh.T_global)
+    buf, mid = sh.halo_buffer(g.B, S, C, ops.act_dtype, xs.device)
     ga, be, eps = p.t_gn1
     h = ops.groupnorm(xs, None, ga, be, g.n, S, eps=eps, silu=True, out=mid, stats=xs_stats, **gn_kw)
-    epi = {}
-    if p.t_emb_off >= 0:
-        epi = dict(add=env.emb_all[:, p.t_emb_off:], add_rpg=S, add_ld=env.emb_all.stride(0))
-    st2, gkw = _gn_producer(ops, g.n // T, T * S, p.t_w1.shape[-2], xs.device, level=2)
-    if sh is None:
-        h = ops.convt3(h, p.t_w1, p.t_b1, T, S, **epi, **gkw)
-    else:
-        h = sh.convt3(ops, buf, p.t_w1, p.t_b1, g, **epi, **gkw)
+    h = sh.convt3(ops, buf, p.t_w1, p.t_b1, g, **epi1, **gkw)
     ga, be, eps = p.t_gn2
     h = ops.groupnorm(h, None, ga, be, g.n, S, eps=eps, silu=True, out=mid, stats=st2, **gn_kw)
-    epi = dict(res1=xs)
-    if coef is not None:
-        epi.update(coef=coef, coef_rpg=S)
-    else:
-        epi.update(c_acc=c_acc, c_res1=1.0)
-    if sh is None:
-        return ops.convt3(h, p.t_w2, p.t_b2, T, S, **epi)
-    return sh.convt3(ops, buf, p.t_w2, p.t_b2, g, **epi)
+    return sh.convt3(ops, buf, p.t_w2, p.t_b2, g, **epi2)
 
 
 def unet_resblock(env: Env, g: Geo, p: ResPack, x1, x2=None):

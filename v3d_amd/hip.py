@@ -16,7 +16,7 @@ from .ops import GemmCall, OpsBase
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("V3D_HIP_LIB") or os.path.join(_HERE, "lib", "libv3d_hip.so")     # (override: A/B runs of two builds on one box)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i64, c_i32, c_f32, c_f64, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_void_p
 
@@ -37,7 +37,10 @@ class _GemmArgs(C.Structure):
         ("batch", c_i32), ("pad_mode", c_i32),
         ("sA", c_i64), ("sW", c_i64), ("sO", c_i64),
         ("halo_rows", c_i64),
-        ("gn_stats", c_vp), ("gn_rps", c_i64), ("gn_cpg", c_i32), ("reserved0", c_i32),
+        ("gn_stats", c_vp), ("gn_rps", c_i64), ("gn_cpg", c_i32), ("gn_in_silu", c_i32),
+        ("gn_nslots", c_i64),
+        ("gn_in_table", c_vp), ("gn_in_rps", c_i64), ("gn_in_rows", c_i64),
+        ("A2", c_vp), ("K1", c_i64), ("lda2", c_i64),
     ]
 
 
@@ -53,9 +56,10 @@ SIGNATURES = {
     "v3d_ln_ff_fused": (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32, c_f32,
                                 c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "v3d_ln_proj": (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp]),
-    "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp]),
-    "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i64,
-                                    c_f64, c_f32, c_i32, c_vp]),
+    "v3d_gemm_gn_in_supported": (c_i32, [C.POINTER(_GemmArgs)]),
+    "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_i64, c_vp]),
+    "v3d_groupnorm_finalize": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_f64, c_f32, c_vp, c_vp]),
+    "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "v3d_layernorm": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp]),
     "v3d_attn_spatial": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "v3d_attn_temporal": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64,
@@ -191,13 +195,13 @@ class HipOps(OpsBase):
                 kw["coef"] = g.coef.reshape(-1, 3)[r0 // g.coef_rpg:].contiguous()
             if g.gn_stats is not None:
                 kw["gn_stats"] = g.gn_stats[r0 // g.gn_rps:]
+            if g.gn_in is not None:
+                raise RuntimeError("gemm: gn_in is not defined for operands beyond one buffer descriptor (normalise with groupnorm_apply first)")
             self.gemm(dataclasses.replace(g, **kw))
         return True
 
-    def gemm(self, g: GemmCall):
+    def _gemm_args(self, g: GemmCall) -> _GemmArgs:
         bf, f32 = torch.bfloat16, torch.float32
-        if self._gemm_in_row_chunks(g):
-            return
         a = _GemmArgs()
         self._req(g.A, bf, "gemm.A")
         self._req(g.W, bf, "gemm.W")
@@ -230,7 +234,13 @@ class HipOps(OpsBase):
         a.halo_rows = g.halo_rows
         if g.gn_stats is not None:
             self._req_c(g.gn_stats, f32, "gemm.gn_stats")
-            a.gn_stats, a.gn_rps, a.gn_cpg = g.gn_stats.data_ptr(), g.gn_rps, g.gn_cpg
+            a.gn_stats, a.gn_rps, a.gn_cpg, a.gn_nslots = g.gn_stats.data_ptr(), g.gn_rps, g.gn_cpg, g.gn_stats.shape[1]
+        if g.gn_in is not None:
+            self._req_c(g.gn_in, f32, "gemm.gn_in")
+            a.gn_in_table, a.gn_in_rps, a.gn_in_rows, a.gn_in_silu = g.gn_in.data_ptr(), g.gn_in_rps, g.gn_in.shape[0], int(g.gn_in_silu)
+        if g.A2 is not None:
+            self._req(g.A2, bf, "gemm.A2")
+            a.A2, a.K1, a.lda2 = g.A2.data_ptr(), g.A.shape[-1], g.A2.stride(-2)
         if g.batch > 1:
             if g.mode != 0:
                 raise RuntimeError("gemm: batching is only defined for LINEAR mode")
@@ -239,7 +249,20 @@ class HipOps(OpsBase):
             a.sO = g.out.stride(0) if g.out.dim() == 3 else 0
             if g.out.dim() != 3:
                 raise RuntimeError("gemm: batched out must be 3-D")
+        return a
+
+    def gemm(self, g: GemmCall):
+        if self._gemm_in_row_chunks(g):
+            return
+        a = self._gemm_args(g)
         self._check(self.lib.v3d_gemm(C.byref(a), self._stream()), "v3d_gemm")
+
+    def gemm_gn_in_supported(self, g: GemmCall) -> bool:
+        """Would v3d_gemm run this call (with its gn_in table / second source) on a kernel that normalises the operand in flight?"""
+        if g.gn_in is None or g.A.dim() != 2 or g.A.shape[0] * g.A.stride(0) * 2 > self._MAX_OPERAND_BYTES:
+            return False
+        a = self._gemm_args(g)
+        return bool(self.lib.v3d_gemm_gn_in_supported(C.byref(a)))
 
     def groupnorm_stats(self, x1, x2, stats, n_img, S, groups, imgs_per_stat):
         bf = torch.bfloat16
@@ -248,19 +271,35 @@ class HipOps(OpsBase):
             self._req_c(x2, bf, "gn.x2")
         self._req_c(stats, torch.float32, "gn.stats")
         self._check(self.lib.v3d_groupnorm_stats(x1.data_ptr(), x1.shape[-1], _ptr(x2), 0 if x2 is None else x2.shape[-1],
-                                                 stats.data_ptr(), n_img, S, groups, imgs_per_stat, self._stream()),
+                                                 stats.data_ptr(), stats.shape[1], n_img, S, groups, imgs_per_stat, self._stream()),
                     "v3d_groupnorm_stats")
 
-    def groupnorm_apply(self, x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu):
+    def groupnorm_finalize(self, stats, sums, gamma, beta, count, eps, table):
+        """stats [n_stat, nslots, groups, 2] fp32 (or None: read `sums`), sums [n_stat, groups, 2] fp64 (or None), table [n_stat, C, 2] fp32 (or None)."""
+        f32 = torch.float32
+        if stats is not None:
+            self._req_c(stats, f32, "gn.stats")
+        if sums is not None:
+            self._req_c(sums, torch.float64, "gn.sums")
+        ref = stats if stats is not None else sums
+        n_stat, groups = ref.shape[0], ref.shape[-2]
+        Cc = 0
+        if table is not None:
+            self._req_c(gamma, f32, "gn.gamma"); self._req_c(beta, f32, "gn.beta"); self._req_c(table, f32, "gn.table")
+            Cc = gamma.numel()
+        self._check(self.lib.v3d_groupnorm_finalize(_ptr(stats), 0 if stats is None else stats.shape[1], _ptr(sums), n_stat, groups,
+                                                    _ptr(gamma) if table is not None else None, _ptr(beta) if table is not None else None, Cc,
+                                                    float(count), float(eps), _ptr(table), self._stream()), "v3d_groupnorm_finalize")
+
+    def groupnorm_apply(self, x1, x2, table, out, n_img, S, imgs_per_stat, silu):
         bf, f32 = torch.bfloat16, torch.float32
         self._req_c(x1, bf, "gn.x1")
         if x2 is not None:
             self._req_c(x2, bf, "gn.x2")
-        self._req_c(stats, f32, "gn.stats"); self._req_c(gamma, f32, "gn.gamma"); self._req_c(beta, f32, "gn.beta")
+        self._req_c(table, f32, "gn.table")
         self._req_c(out, bf, "gn.out")
         self._check(self.lib.v3d_groupnorm_apply(x1.data_ptr(), x1.shape[-1], _ptr(x2), 0 if x2 is None else x2.shape[-1],
-                                                 stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                                 n_img, S, groups, imgs_per_stat, float(count), float(eps), int(silu),
+                                                 table.data_ptr(), out.data_ptr(), n_img, S, imgs_per_stat, int(silu),
                                                  self._stream()), "v3d_groupnorm_apply")
 
     def layernorm(self, x, gamma, beta, out, eps, add=None, add_rpg=0, add_ld=0, xsum_out=None):

@@ -15,7 +15,6 @@ from typing import Optional
 import torch
 
 GEMM_LINEAR, GEMM_CONV3X3, GEMM_CONVT3 = 0, 1, 2
-GN_SLOTS = 32   # V3D_GN_SLOTS: partial-sum slots per GroupNorm statistics group
 
 
 @dataclasses.dataclass
@@ -61,9 +60,15 @@ class GemmCall:
     a_rows: int = 0          # 0 -> A.shape[-2]
     batch: int = 1           # batched (LINEAR only): A / W / out may be 3-D [batch, rows, cols]; a 2-D operand is shared
     halo_rows: int = 0       # CONVT3 split-halo layout (frame sharding): B*S halo rows on either side of the M local rows
-    gn_stats: Optional[torch.Tensor] = None   # fp32 [M / gn_rps, GN_SLOTS, 32, 2]: GroupNorm partial sums of the output (epilogue)
+    gn_stats: Optional[torch.Tensor] = None   # fp32 [M / gn_rps, nslots, 32, 2]: GroupNorm partial sums of the output (epilogue)
     gn_rps: int = 0
     gn_cpg: int = 0
+    # GroupNorm (+SiLU) of the INPUT in the operand path: A (| A2, channel-concatenated) hold the raw tensor, gn_in = the (scale, shift)
+    # table [n_stat, K, 2] of groupnorm_finalize, one row per gn_in_rps source rows
+    gn_in: Optional[torch.Tensor] = None
+    gn_in_rps: int = 0
+    gn_in_silu: bool = True
+    A2: Optional[torch.Tensor] = None
 
 
 class OpsBase:
@@ -79,7 +84,7 @@ class OpsBase:
     def zeros(self, shape, dtype=torch.float32, device=None):
         return torch.zeros(shape, dtype=dtype, device=device if device is not None else self.device)
 
-    _ZERO_ARENA_FLOATS = 8 << 20   # 32 MiB: about one network evaluation's worth of GroupNorm partial-sum buffers
+    _ZERO_ARENA_FLOATS = 32 << 20   # 128 MiB: about one network evaluation's worth of GroupNorm partial-sum buffers (slots: one per writer)
 
     def begin_evaluation(self, device):
         """Called at the top of every network evaluation (U-Net, VAE decoder / encoder, CLIP tower): rewinds the zero-initialised
@@ -102,8 +107,8 @@ class OpsBase:
     def zeros_f32_pooled(self, shape, device):
         """Zero-initialised fp32 scratch carved out of a pre-zeroed arena: one fill kernel per evaluation instead of one per
         request (the per-GroupNorm `torch.zeros` fills were 3000 launches / 14 ms per sample in the rocprof trace).  A slice is
-        handed out once per evaluation (`begin_evaluation` rewinds); an exhausted arena is replaced by a fresh, larger one (the
-        old slices keep the old storage alive) - except under stream capture, where a new allocation would belong to the
+        handed out once per evaluation (`begin_evaluation` rewinds); an exhausted arena is replaced by one at least twice as large (the
+        old one is kept alive: slices and captured graphs may still point into it) - except under stream capture, where a new allocation would belong to the
         graph's private pool: there the request falls back to its own `torch.zeros` (a memset node)."""
         n = 1
         for d in shape:
@@ -114,15 +119,26 @@ class OpsBase:
         if arena is None or arena[1] + n > arena[0].numel():
             if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
                 return torch.zeros(shape, dtype=torch.float32, device=device)
-            arena = [torch.zeros(max(n, self._ZERO_ARENA_FLOATS), dtype=torch.float32, device=device), 0]
+            # grow geometrically, and never drop a retired arena: a HIP graph captured earlier keeps raw pointers into it (its memset
+            # node and its kernels would otherwise touch memory the caching allocator has handed to someone else)
+            grown = max(n, self._ZERO_ARENA_FLOATS, 0 if arena is None else 2 * arena[0].numel())
+            if arena is not None:
+                self.__dict__.setdefault("_retired_arenas", []).append(arena[0])
+            arena = [torch.zeros(grown, dtype=torch.float32, device=device), 0]
             arenas[key] = arena
         t = arena[0][arena[1]:arena[1] + n].view(shape)
         arena[1] += (n + 63) // 64 * 64
         return t
 
-    def gn_stats_buffer(self, n_stat, device, groups=32):
-        """Zeroed partial-sum buffer [n_stat, GN_SLOTS, groups, 2] of one GroupNorm (v3d_groupnorm_stats / the gn_stats epilogue)."""
-        return self.zeros_f32_pooled((n_stat, GN_SLOTS, groups, 2), device)
+    @staticmethod
+    def gn_nslots(rps, imgs_per_stat=1):
+        """Slots per statistics group: one per writer.  Stand-alone statistics kernel: imgs_per_stat x (blocks per image, the library fits
+        its grid to what it gets); GEMM epilogues: one per 64+-row wave tile inside the group (+2 for the straddlers)."""
+        return max(8 * imgs_per_stat, rps // 64 + 2)
+
+    def gn_stats_buffer(self, n_stat, device, groups=32, *, rps, imgs_per_stat=1):
+        """Zeroed partial-sum buffer [n_stat, nslots, groups, 2] of one GroupNorm (v3d_groupnorm_stats / the gn_stats epilogue)."""
+        return self.zeros_f32_pooled((n_stat, self.gn_nslots(rps, imgs_per_stat), groups, 2), device)
 
     # ---- composite helpers shared by every backend ------------------------------------------------
     def linear(self, x2d, w, bias=None, *, out=None, out_dtype=None, geglu=False, **epi):
@@ -163,26 +179,46 @@ class OpsBase:
                            tmax=tmax, a_row0=a_row0, halo_rows=halo_rows, **epi))
         return out
 
-    def groupnorm(self, x1, x2, gamma, beta, n_img, S, *, eps, silu, imgs_per_stat=1, groups=32, stats_hook=None,
-                  count_imgs=None, out=None, stats=None):
-        """GroupNorm(+SiLU) over channels-last x1 (and optional channel-concatenated x2).
+    def groupnorm_table(self, x1, x2, gamma, beta, n_img, S, *, eps, imgs_per_stat=1, groups=32, stats_hook=None, count_imgs=None, stats=None):
+        """Statistics of GroupNorm over channels-last x1 (| x2) -> the (scale, shift) table [n_stat, C, 2] its normalisation amounts to
+        (y = x * scale + shift per (statistics group, channel)): what groupnorm_apply and the operand-path consumers (GemmCall.gn_in) take.
 
-        stats_hook(stats) lets the frame-sharded runtime all-reduce (sum, sumsq) between the two kernels;
-        count_imgs = number of images (global) contributing to one statistics group.
-        """
+        stats: partial sums already gathered by the epilogue of the GEMM that produced x1 (GemmCall.gn_stats).
+        stats_hook(sums fp64 [n_stat, groups, 2]) lets the frame-sharded runtime all-reduce (sum, sumsq) over ranks;
+        count_imgs = number of images (global) contributing to one statistics group."""
         C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
-        if stats is None:      # else: the partial sums were accumulated by the epilogue of the GEMM that produced x1 (GemmCall.gn_stats)
-            stats = self.gn_stats_buffer(n_img // imgs_per_stat, x1.device, groups)
+        n_stat = n_img // imgs_per_stat
+        if stats is None:
+            stats = self.gn_stats_buffer(n_stat, x1.device, groups, rps=imgs_per_stat * S, imgs_per_stat=imgs_per_stat)
             self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
-        if stats_hook is not None:
-            stats = stats_hook(stats)
         if count_imgs is None:
             count_imgs = imgs_per_stat
         count = float(count_imgs) * S * (C // groups)
+        table = self.empty((n_stat, C, 2), torch.float32, x1.device)
+        if stats_hook is None:
+            self.groupnorm_finalize(stats, None, gamma, beta, count, eps, table)
+        else:
+            sums = self.empty((n_stat, groups, 2), torch.float64, x1.device)
+            self.groupnorm_finalize(stats, sums, None, None, count, eps, None)
+            sums = stats_hook(sums)
+            self.groupnorm_finalize(None, sums, gamma, beta, count, eps, table)
+        return table
+
+    def groupnorm(self, x1, x2, gamma, beta, n_img, S, *, eps, silu, imgs_per_stat=1, groups=32, stats_hook=None,
+                  count_imgs=None, out=None, stats=None, table=None):
+        """GroupNorm(+SiLU) over channels-last x1 (and optional channel-concatenated x2): statistics -> table -> apply."""
+        C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+        if table is None:
+            table = self.groupnorm_table(x1, x2, gamma, beta, n_img, S, eps=eps, imgs_per_stat=imgs_per_stat, groups=groups,
+                                         stats_hook=stats_hook, count_imgs=count_imgs, stats=stats)
         if out is None:
             out = self.empty((n_img * S, C), self.act_dtype, x1.device)
-        self.groupnorm_apply(x1, x2, stats, gamma, beta, out, n_img, S, groups, imgs_per_stat, count, eps, silu)
+        self.groupnorm_apply(x1, x2, table, out, n_img, S, imgs_per_stat, silu)
         return out
+
+    def gemm_gn_in_supported(self, g: "GemmCall") -> bool:
+        """Backends that can normalise a GEMM operand in flight answer per call (HipOps asks the library)."""
+        return False
 
 
 _ACTIVE: Optional[OpsBase] = None
