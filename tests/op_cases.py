@@ -472,7 +472,7 @@ def all_cases(full: bool = True):
         ("gn3d_offcentre_100", case_groupnorm, dict(n_img=6, S=256, C1=320, imgs_per_stat=3, mean=100.0, std=0.5, seed=13), TOL_BF16),
         # GroupNorm + SiLU in the operand path of the LDS-haloed convolutions (conv.hip)
         ("conv_gn_64_plain", case_conv_gn, dict(N=320, C1=320, conv=(3, 64, 64)), TOL_BF16),
-        ("conv_gn_64_straddle_add_gnout", case_conv_gn, dict(N=320, C1=64, conv=(5, 64, 64), add=True, gn_out=True, seed=1), TOL_BF16),
+        ("conv_gn_64_straddle_add_gnout", case_conv_gn, dict(N=320, C1=64, conv=(6, 64, 64), add=True, gn_out=True, seed=1), TOL_BF16),
         ("conv_gn_64_concat_res", case_conv_gn, dict(N=320, C1=64, C2=32, conv=(3, 64, 64), res=1, seed=2), TOL_BF16),
         ("conv_gn_32_n640", case_conv_gn, dict(N=640, C1=96, conv=(6, 32, 32), add=True, gn_out=True, seed=3), TOL_BF16),
         ("conv_gn_16_n1280", case_conv_gn, dict(N=1280, C1=64, C2=64, conv=(12, 16, 16), res=1, gn_out=True, seed=4), TOL_BF16),

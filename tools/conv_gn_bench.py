@@ -81,6 +81,10 @@ def main():
               f"   fused {t_fused:7.1f} us ({flop / t_fused / 1e6 if ok else 0:6.0f} TF/s)   x{(t_apply + t_conv) / t_fused if ok else 0:.2f}", flush=True)
 
     # [V3D] ResBlock convolutions of the U-Net at batch 36 (input / output blocks; [ba] = in_layers conv with emb add, [br] = out_layers conv with skip)
+    case("c3_L0_320_bare", 320, 320, conv=(36, 64, 64), gn_out=False)        # epilogue variants of one shape: bias only
+    case("c3_L0_320_gnout", 320, 320, conv=(36, 64, 64))
+    case("c3_L0_320_addonly", 320, 320, conv=(36, 64, 64), add=True, gn_out=False)
+    case("c3_L0_320_resonly", 320, 320, conv=(36, 64, 64), res=True, gn_out=False)
     case("c3_L0_320_in", 320, 320, conv=(36, 64, 64), add=True)
     case("c3_L0_320_out", 320, 320, conv=(36, 64, 64), res=True)
     case("c3_L0_concat640", 320, 320, 320, conv=(36, 64, 64), add=True)

@@ -42,7 +42,17 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+    """experiments=True: a second library (lib_exp/libv3d_hip_exp.so, -DV3D_EXPERIMENTS) whose GEMM / convolution kernels honour the
+    V3D_GEMM_ABLATE timing switches (skip MFMAs / DMA / fragment reads / barriers: results are garbage by design).  Select it with
+    V3D_HIP_LIB=<path>; the product library never contains those switches."""
+    if experiments:
+        return _build(force, verbose, os.path.join(HERE, "lib_exp"), "libv3d_hip_exp.so", ["-DV3D_EXPERIMENTS"])
+    return _build(force, verbose, LIBDIR, "libv3d_hip.so", [])
+
+
+def _build(force, verbose, LIBDIR, libname, extra) -> str:
+    LIB = os.path.join(LIBDIR, libname)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -56,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[v3d_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -79,4 +89,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

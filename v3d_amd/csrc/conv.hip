@@ -23,6 +23,14 @@
 
 #include "gemm_common.h"
 
+// Timing experiments (tools/conv_ablate.sh, results in profiles/r03_conv_ablation.txt): -DCONV_ABL=<bits> builds of this file only -
+// compile-time, so the measured loop carries no extra branches.  1 no epilogue, 2 no MFMA, 4 no weight DMA, 4096 no fragment reads,
+// 8192 no halo DMA, 16384 no normalisation chain, 32768 no per-step waits / barrier.  The product build has CONV_ABL = 0.
+#ifndef CONV_ABL
+#define CONV_ABL 0
+#endif
+#define CABL(bit) ((CONV_ABL & (bit)) != 0)
+
 namespace {
 
 enum { HM_CONV = 0, HM_TEMP = 1 };
@@ -58,6 +66,51 @@ struct XfState {
     u32x4 out;
     float x0, x1, y0, y1, t0, t1;
 };
+
+// retire fragment F (16 rows x the wave's 80 channels) of a finished tile, residual rows of fragment F + 1 in flight meanwhile.  The pieces
+// travel BY VALUE through the recursion (gemm.hip v3_retire_chunks: captured by reference in a lambda they went through a stack array -
+// every residual load was followed by s_waitcnt vmcnt(0) and a scratch store: 18 serialised memory round trips per tile, the [res]
+// convolutions ran 50 us slower than their v3 twins).  frow(f) = first output row of fragment f; slot = the wave tile's statistics slot.
+struct RetireGeo {
+    long long mw0;      // first row of the wave tile (3x3) / of its first frame (temporal)
+    long long S;        // temporal: rows per frame
+    unsigned tslot;     // temporal: the wave tile's statistics slot
+};
+template <int HM>
+__device__ __forceinline__ long long frag_row0(const RetireGeo& q, int f) {
+    return HM == 0 ? q.mw0 + f * 16 : q.mw0 + (long long)(f / 2) * q.S + (f % 2) * 16;
+}
+template <int F, int MF, int NF, int HM, bool GN>
+__device__ __forceinline__ void halo_retire(const GP& p, f32x4 (&acc)[MF][NF], const RetireGeo& q, long long nw0, int lane, unsigned char* estage,
+                                            u32x4 c0, u32x4 c1, u32x4 c2, bool res_pre, const float4 (&bv)[NF], GnAcc<GN ? NF : 1>& gn) {
+    if constexpr (F < MF) {
+        constexpr int WMR = MF * 16;
+        const long long m0f = frag_row0<HM>(q, F);
+        u32x4 n0 = c0, n1 = c1, n2 = c2;
+        if constexpr (F + 1 < MF) {
+            if (res_pre) {
+                const long long m1 = frag_row0<HM>(q, F + 1);
+                n0 = load_res_piece<0, 1, NF, false>(p, m1, nw0, lane);
+                n1 = load_res_piece<1, 1, NF, false>(p, m1, nw0, lane);
+                n2 = load_res_piece<2, 1, NF, false>(p, m1, nw0, lane);
+            }
+        }
+        epilogue<1, NF, false, true, true, 16, GN>(p, *reinterpret_cast<f32x4(*)[1][NF]>(&acc[F]), m0f, nw0, 0, lane, estage, c0, c1, c2, res_pre, bv, true, &gn);
+        if constexpr (GN) {
+            // writer = this wave tile's run of rows inside one statistics group; its slot is unique inside the group (gemm_common.h gn_flush)
+            const long long sid = m0f / p.gn_rps;
+            bool flush = F + 1 == MF;
+            unsigned slot = q.tslot;
+            if (HM == 0) {
+                flush = flush || (m0f + 16) / p.gn_rps != sid;
+                const long long first = q.mw0 / p.gn_rps == sid ? q.mw0 - sid * p.gn_rps : 0;
+                slot = (unsigned)((first + WMR - 1) / WMR);
+            }
+            if (flush) gn_flush<NF>(p, gn, sid, nw0, lane, estage, slot);
+        }
+        halo_retire<F + 1, MF, NF, HM, GN>(p, acc, q, nw0, lane, estage, n0, n1, n2, res_pre, bv, gn);
+    }
+}
 
 template <int HM, int W_, bool XF, bool GN>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
@@ -98,113 +151,116 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     const bufrsrc_t rsW = make_rsrc(p.W, p.w_bytes);
     const int prow = lane >> 2;
     const unsigned kchunk_w = (unsigned)(((lane & 3) ^ wswz(prow)) * 16);
-    unsigned voffW[3];
+    const unsigned voffW = (unsigned)(prow * (int)p.ldw * 2) + kchunk_w;     // per-lane part of a weight piece's source offset (row inside the piece, k-chunk)
     int w_it = 0, w_c = 0;                                // weight cursor: tile, chunk (its tap is static in the unrolled step bodies)
+    int w_n0 = 0;                                         // first output channel of the cursor's tile
     const unsigned tap_bytes = (unsigned)(p.N * p.ldw * 2);
+    const int row16_bytes = (int)(16 * p.ldw * 2);
     auto set_wtile = [&](int it) __attribute__((always_inline)) {
         int tm;
         long long n0 = 0;
-        if (it < my_tiles) tile_origin(it, tm, n0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const long long n = n0 + (wave + NW * i) * 16 + prow;
-            voffW[i] = (it < my_tiles && n < p.N) ? (unsigned)(n * p.ldw * 2) + kchunk_w : kInvalid;
-        }
+        if (it < my_tiles) tile_origin(it, tm, n0);      // (past the last tile: harmless re-reads of tile column 0 keep the DMA count constant)
+        w_n0 = (int)n0;
     };
     auto issue_w = [&](int stage, int ltap) __attribute__((always_inline)) {
-        const int so = (int)(ltap * tap_bytes) + w_c * 64;
+        if (CABL(4)) return;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) {
+            // scalar offset: tap, chunk and the piece's 16-row block (N % 320 == 0: every row of the tile exists)
+            const int so = (int)(ltap * tap_bytes) + w_c * 64 + (w_n0 / 16 + wave + NW * i) * row16_bytes;
             if (i < 2 || grp == 0)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + RING_OFF + stage * WSTAGE + (wave + NW * i) * 1024), 16,
-                                                         (int)voffW[i], so, 0, 0);
+                                                         (int)voffW, so, 0, 0);
+        }
     };
     // ---------------------------------------------------------------- halo loader (LA chunks ahead)
     const bufrsrc_t rsA1 = make_rsrc(p.A, p.a_bytes);
     const bufrsrc_t rsA2 = make_rsrc(p.A2 ? p.A2 : p.A, p.A2 ? p.a2_bytes : p.a_bytes);
     const bufrsrc_t rsT = make_rsrc(p.gn_in ? (const void*)p.gn_in : (const void*)p.A, p.gn_in ? p.gn_in_bytes : 0u);
     int h_it = 0, h_c = 0, h_buf = 0;                    // halo cursor: tile, chunk, LDS image it writes
-    unsigned hsrow[HPW];                                  // source pixel row of this lane's halo pixel of piece i (kInvalid: padding)
-    unsigned htab[HPW];                                   // LDS byte address of its (scale, shift) pairs: table slot (+256: second statistics group) or the zero page
-    unsigned hstatA = 0, hstatB = 0;
-    int h_tab = 0;                                        // table slot the next issue fills
-    unsigned latch_base = 0, latch_tab[HPW];              // image / table addresses of the last issue, picked up by its normalisation chain
+    // per-tile state of the cursor, all wave-uniform (the per-lane source rows are recomputed where they are used: a dozen VALU per piece and
+    // chunk against registers held through every step)
+    struct HTile {
+        int live;          // the cursor is inside this block's tiles
+        int fr0;           // 3x3: first flat image row of the tile;  temporal: sample * T + first frame of the tile's frame block
+        int frB;           // 3x3: first flat image row of the halo's SECOND statistics group (image);  temporal: position block * 32
+        unsigned statA;    // (scale, shift) rows of the halo's first / last source row
+        unsigned statB;
+    };
+    HTile ht = {0, 0, 0, 0u, 0u}, xt = {0, 0, 0, 0u, 0u};      // cursor's tile / the tile of the image issued last (picked up by its normalisation chain)
+    int h_tab = 0, x_tab = 0;                             // table slot the next issue fills / the last issue filled
+    unsigned latch_base = 0;
     // piece i of this wave = halo pixel rows (wave + 8 i) * 16 .. + 15; the lane holds 16 bytes of pixel row + (lane >> 2).  Pieces start at
     // multiples of 16 rows, so the swizzle (bit 2 of the pixel row) - and with it the logical 16-byte chunk (8 channels) the lane holds - is
     // the same for every piece
     const int hchunkpos = (lane & 3) ^ hswz(lane >> 2);
     const unsigned hvec0 = (unsigned)(wave * 1024 + lane * 16);      // LDS byte offset of the lane's vector of piece 0 inside a halo image
-    const unsigned tabslot0 = (unsigned)(TAB_OFF + wave * 512 * G::NTAB);
     auto set_htile = [&](int it) __attribute__((always_inline)) {
         int tm = 0;
         long long n0;
-        const bool live = it < my_tiles;
-        if (live) tile_origin(it, tm, n0);
-        long long rowA = -1, rowB = -1;                   // first / last valid source row of the halo (wave-uniform by construction below)
+        ht.live = it < my_tiles;
+        if (ht.live) tile_origin(it, tm, n0);
+        const long long rps = p.gn_in_rps > 0 ? p.gn_in_rps : 1;
         if (HM == HM_CONV) {
-            const long long fr0 = (long long)tm * (BM / W_);                  // first flat image row of the tile
-            const long long nfr = p.M / W_;
-#pragma unroll
-            for (int i = 0; i < HPW; ++i) {
-                const int hp = (wave + NW * i) * 16 + (lane >> 2);
-                const int line = hp / LINE, x = hp - line * LINE - 1;
-                const long long fr = fr0 - 1 + line;
-                const bool ok = live && x >= 0 && x < W_ && fr >= 0 && fr < nfr && line < G::NLINES;
-                hsrow[i] = ok ? (unsigned)(fr * W_ + x) : kInvalid;
-            }
-            const long long f_lo = fr0 - 1 < 0 ? 0 : fr0 - 1, f_hi = fr0 + BM / W_ >= nfr ? nfr - 1 : fr0 + BM / W_;
-            rowA = f_lo * W_;
-            rowB = f_hi * W_;
+            const int fr0 = tm * (BM / W_);                                    // first flat image row of the tile
+            const int nfr = (int)(p.M / W_);
+            const int f_lo = fr0 - 1 < 0 ? 0 : fr0 - 1, f_hi = fr0 + BM / W_ >= nfr ? nfr - 1 : fr0 + BM / W_;
+            ht.fr0 = fr0;
+            ht.statA = (unsigned)((long long)f_lo * W_ / rps);
+            ht.statB = (unsigned)((long long)f_hi * W_ / rps);
+            ht.frB = (int)(((long long)ht.statA + 1) * rps / W_);
         } else {
             // tile row-block tm = (sample b, frame block tb, position block sb), positions fastest
             const int sb = tm % sblocks, tb = (tm / sblocks) % tblocks, b = tm / (sblocks * tblocks);
-#pragma unroll
-            for (int i = 0; i < HPW; ++i) {
-                const int hp = (wave + NW * i) * 16 + (lane >> 2);
-                const int line = hp >> 5, s = hp & 31;
-                const int fr = tb * 6 - 1 + line;                              // frame of the sample
-                const bool ok = live && fr >= p.tmin && fr <= p.tmax;
-                long long row = ((long long)b * p.T + fr) * p.S + sb * 32 + s;
-                if (p.halo_rows > 0) {                                         // frame sharding: frame -1 / T live in the slabs around the local frames
-                    if (fr < 0) row = (long long)b * p.S + sb * 32 + s - p.halo_rows;
-                    else if (fr >= p.T) row = p.M + (long long)b * p.S + sb * 32 + s;
-                }
-                hsrow[i] = ok ? (unsigned)(row + p.a_row0) : kInvalid;
-            }
-            rowA = rowB = (long long)b * p.T * p.S;                            // one statistics group per sample (the 3-D GroupNorm)
+            ht.fr0 = b * p.T + tb * 6;
+            ht.frB = sb * 32;
+            ht.statA = ht.statB = (unsigned)(((long long)b * p.T * p.S) / rps);          // one statistics group per sample (the 3-D GroupNorm)
         }
-        hstatA = (unsigned)__builtin_amdgcn_readfirstlane((int)(rowA / (p.gn_in_rps > 0 ? p.gn_in_rps : 1)));
-        hstatB = (unsigned)__builtin_amdgcn_readfirstlane((int)(rowB / (p.gn_in_rps > 0 ? p.gn_in_rps : 1)));
-        if (XF) {
-#pragma unroll
-            for (int i = 0; i < HPW; ++i) {
-                unsigned st = hstatA;
-                if (HM == HM_CONV && hsrow[i] != kInvalid) st = (unsigned)((long long)hsrow[i] / p.gn_in_rps);
-                htab[i] = hsrow[i] == kInvalid ? (unsigned)ZERO_OFF + (unsigned)hchunkpos * 64u
-                                               : tabslot0 + (st != hstatA ? 256u : 0u) + (unsigned)hchunkpos * 64u;
+    };
+    // source pixel row of this lane's halo pixel of piece i in tile t (kInvalid: padding / outside the tensor); second = it belongs to statB
+    auto halo_row = [&](const HTile& t, int i, bool& second) __attribute__((always_inline)) -> unsigned {
+        const int hp = (wave + NW * i) * 16 + (lane >> 2);
+        second = false;
+        if (HM == HM_CONV) {
+            const int line = hp / LINE, x = hp - line * LINE - 1;
+            const int fr = t.fr0 - 1 + line;
+            const int nfr = (int)(p.M / W_);
+            const bool ok = t.live && x >= 0 && x < W_ && fr >= 0 && fr < nfr && line < G::NLINES;
+            second = fr >= t.frB;
+            return ok ? (unsigned)(fr * W_ + x) : kInvalid;
+        } else {
+            const int line = hp >> 5, sp = hp & 31;
+            const int b = t.fr0 / p.T, f = t.fr0 - b * p.T - 1 + line;          // frame of the sample
+            const bool ok = t.live && f >= p.tmin && f <= p.tmax;
+            long long row = ((long long)t.fr0 - 1 + line) * p.S + t.frB + sp;
+            if (p.halo_rows > 0) {                                             // frame sharding: frame -1 / T live in the slabs around the local frames
+                if (f < 0) row = (long long)b * p.S + t.frB + sp - p.halo_rows;
+                else if (f >= p.T) row = p.M + (long long)b * p.S + t.frB + sp;
             }
+            return ok ? (unsigned)(row + p.a_row0) : kInvalid;
         }
     };
     auto issue_halo = [&]() __attribute__((always_inline)) {
+        if (CABL(8192)) return;
         if (h_c == 0) set_htile(h_it);
         const bool second = h_c >= k1chunks;
         const int cc = second ? h_c - k1chunks : h_c;
         const unsigned ld2 = (unsigned)((second ? p.lda2 : p.lda) * 2);
         if (XF && lane < 32) {
             // (scale, shift) of this chunk's 32 channels for the (at most two) statistics groups of the halo: 2 x 256 B
-            const unsigned st = lane < 16 ? hstatA : hstatB;
+            const unsigned st = lane < 16 ? ht.statA : ht.statB;
             const unsigned vo = (unsigned)(((long long)st * p.K + (long long)h_c * 32) * 8) + (unsigned)(lane & 15) * 16u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (__attribute__((address_space(3))) void*)(lds + TAB_OFF + (wave * G::NTAB + h_tab) * 512), 16, (int)(h_it < my_tiles ? vo : kInvalid), 0, 0, 0);
         }
         latch_base = (unsigned)(HALO_OFF + h_buf * HBYTES);
-        if (G::NTAB == 2) {
-#pragma unroll
-            for (int i = 0; i < HPW; ++i) latch_tab[i] = htab[i] + (htab[i] >= (unsigned)TAB_OFF ? (unsigned)(h_tab * 512) : 0u);
-            h_tab ^= 1;
-        }
+        xt = ht;                                          // (the chain of this image starts after the issue: xf_begin picks these up)
+        x_tab = h_tab;
+        if (G::NTAB == 2) h_tab ^= 1;
 #pragma unroll
         for (int i = 0; i < HPW; ++i) {
-            const unsigned vo = hsrow[i] == kInvalid ? kInvalid : hsrow[i] * ld2 + (unsigned)hchunkpos * 16u;
+            bool second_stat;
+            const unsigned row = halo_row(ht, i, second_stat);
+            const unsigned vo = row == kInvalid ? kInvalid : row * ld2 + (unsigned)hchunkpos * 16u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rsA2 : rsA1, (__attribute__((address_space(3))) void*)(lds + HALO_OFF + h_buf * HBYTES + (wave + NW * i) * 1024), 16,
                                                      (int)vo, cc * 64, 0, 0);
         }
@@ -216,13 +272,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     };
     // ---------------------------------------------------------------- the in-place normalisation of the image the loader filled last
     // image being normalised: the one issue_halo wrote at the last issue step
-    unsigned xf_base = 0, xf_tab[HPW];                    // LDS byte address of that image / of each vector's (scale, shift) pairs
+    unsigned xf_base = 0;                                 // LDS byte address of that image
+    HTile ct = {0, 0, 0, 0u, 0u};                         // its tile
+    int c_tab = 0;                                        // its table slot
     XfState xs;
     auto xf_read_vec = [&](int v) __attribute__((always_inline)) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(lds + xf_base + hvec0 + v * 8192);
     };
+    // (scale, shift) x 2 of channel pair e of vector v: the wave's table slot (+256: the halo's second statistics group), or the zero page
+    // for padding pixels (x * 0 + 0 -> SiLU(0) = 0: what the convolution's zero padding is)
+    unsigned ctab[HPW];                                   // (computed once per image in xf_begin: live through the chain's steps only)
     auto xf_read_tab = [&](int v, int e) __attribute__((always_inline)) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(lds + (G::NTAB == 2 ? xf_tab[v] : htab[v]) + e * 16);
+        return *reinterpret_cast<const f32x4*>(lds + ctab[v] + e * 16);
     };
     // OP = 15 * (4 * vector + pair) + stage.  Every result is pinned to its slot by an empty volatile asm: the steps are several basic blocks (the
     // two wave groups pass the barrier at different points) and without the pins MachineSink moves the whole chain down to the block of its
@@ -276,9 +337,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     auto xf_begin = [&]() __attribute__((always_inline)) {          // first reads of an image (its DMA pieces have landed: counted waits below)
         if (XF) {
             xf_base = latch_base;
-            if (G::NTAB == 2) {
+            ct = xt;
+            c_tab = x_tab;
 #pragma unroll
-                for (int i = 0; i < HPW; ++i) xf_tab[i] = latch_tab[i];
+            for (int v = 0; v < HPW; ++v) {
+                bool second;
+                const unsigned row = halo_row(ct, v, second);
+                ctab[v] = (row == kInvalid ? (unsigned)ZERO_OFF : (unsigned)(TAB_OFF + (wave * G::NTAB + c_tab) * 512) + (second ? 256u : 0u)) + (unsigned)hchunkpos * 64u;
             }
             xs.raw = xf_read_vec(0);
             xs.tab = xf_read_tab(0, 0);
@@ -292,6 +357,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 xf[MF], wf[NF];
+#if CONV_ABL
+#pragma unroll
+    for (int i = 0; i < MF; ++i) xf[i] = bf16x8{};      // (the "no fragment reads" timing experiment multiplies whatever is here)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) wf[j] = bf16x8{};
+#endif
     const int wfrag_off = (lane & 15) * ROWB + (((lane >> 4) ^ wswz(lane & 15)) * 16) + wn * WN * ROWB;
     // activation fragment i of the wave = tile rows wm * 96 + i * 16 .. + 15 = 16 consecutive halo pixels starting at pixel row hp0(i) (a
     // multiple of 8, wave-uniform) + tap column dx.  Per-lane byte offset inside a halo image = faddr[dx] (pixel (lane & 15) + dx, chunk
@@ -356,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 constexpr int dy = HM == HM_CONV ? tap / 3 : tap, dx = HM == HM_CONV ? tap % 3 : 0;
                 constexpr int ltap = (tap + NS - 1) % NT;             // the weight loader's tap, NS-1 steps ahead
                 // ---- fragment reads of this step
-                {
+                if (!CABL(4096)) {
                     const unsigned char* sb = lds + RING_OFF + rd * WSTAGE + wfrag_off;
                     // (the per-fragment sums below are loop invariants the compiler would otherwise hoist out of the nine tap bodies and keep in
                     // 30 registers; an opaque copy of the base pins them to the step)
@@ -388,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 // DMA ops younger than the pieces of the NEXT step's weight stage (issued two steps ago): two weight stages, plus the halo
                 // pieces + table piece when one of the last two issue points was a chunk's first step (they are issued AHEAD of that step's weights)
                 constexpr int HL = (tap == 0 || tap == 1) ? HPW + (XF ? 1 : 0) : 0;
-                if (grp == 1) {
+                if (grp == 1 && !CABL(32768)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 + HL) : "memory");
@@ -401,8 +472,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 constexpr int NOPS = HPW * 4 * 15, NSLOT = G::XFN * 30;
                 static_for<0, MF * NF>([&](auto n_) {
                     constexpr int n = decltype(n_)::value, i = n / NF, j = n % NF;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-                    if constexpr (XF && XSTEP >= 0 && XSTEP < G::XFN) {
+                    if (!CABL(2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                    if constexpr (XF && XSTEP >= 0 && XSTEP < G::XFN && !CABL(16384)) {
                         constexpr int s0 = XSTEP * 30 + n;
                         constexpr int o0 = (s0 * NOPS) / NSLOT, o1 = ((s0 + 1) * NOPS) / NSLOT;
                         static_for<o0, o1>([&](auto o) { xf_op(o); });
@@ -411,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 });
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (grp == 0) {
+                if (grp == 0 && !CABL(32768)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (its in-place ds_writes are inline asm)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 3 + HL) : "memory");
                     __builtin_amdgcn_s_barrier();
@@ -426,7 +497,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             }
         }
         // ---------------- tile finished for this group: retire it (v3 epilogue: 16-row chunks through the wave's staging region)
-        {
+        if (CABL(1)) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (sum == 123.456f) reinterpret_cast<float*>(p.out)[0] = sum;   // keeps the accumulators live
+        } else {
             long long mw0;
             if (HM == HM_CONV) {
                 mw0 = (long long)tm * BM + wm * WM;
@@ -435,53 +513,36 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 mw0 = ((long long)b * p.T + tb * 6 + wm * 3) * p.S + sb * 32;      // first row of the wave's 3 frames x 32 positions
             }
             const long long nw0 = e_n0 + wn * WN;
-            float4 bv[NF];
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-                bv[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + (int)nw0 + (lane >> 4) * 4 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool res_pre = p.res1 && !p.out_fp32 && (p.ldr1 % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res1) % 16 == 0);
-            GnAcc<GN ? NF : 1> gn;
-            if constexpr (GN) gn_zero(gn);
             // a fragment's 16 rows are consecutive in both modes (3x3: flat pixels; temporal: 16 of the 32 positions of one frame)
-            auto frag_row0 = [&](int f) __attribute__((always_inline)) -> long long {
-                return HM == HM_CONV ? mw0 + f * 16 : mw0 + (long long)(f / 2) * p.S + (f % 2) * 16;
-            };
-            u32x4 n0 = {0u, 0u, 0u, 0u}, n1 = n0, n2 = n0;
-            if (res_pre) {
-                n0 = load_res_piece<0, 1, NF, false>(p, frag_row0(0), nw0, lane);
-                n1 = load_res_piece<1, 1, NF, false>(p, frag_row0(0), nw0, lane);
-                n2 = load_res_piece<2, 1, NF, false>(p, frag_row0(0), nw0, lane);
+            RetireGeo q;
+            q.mw0 = mw0;
+            q.S = p.S;
+            q.tslot = 0;
+            if (HM == HM_TEMP) {
+                // temporal tiles: the host only offers the statistics epilogue for the 3-D GroupNorm (gn_rps = T * S: the wave's 3 frames x 32
+                // positions lie in one group); writer index inside the sample = (frame block, position block, wave row)
+                const int sb = tm % sblocks, tb = (tm / sblocks) % tblocks;
+                q.tslot = (unsigned)((tb * sblocks + sb) * 2 + wm);
             }
-            static_for<0, MF>([&](auto f_) {
-                constexpr int f = decltype(f_)::value;
-                const long long m0f = frag_row0(f);
-                const u32x4 r0 = n0, r1 = n1, r2 = n2;
-                if constexpr (f + 1 < MF) {
-                    if (res_pre) {       // residual rows one fragment ahead of their use (gemm.hip v3_retire_chunks)
-                        n0 = load_res_piece<0, 1, NF, false>(p, frag_row0(f + 1), nw0, lane);
-                        n1 = load_res_piece<1, 1, NF, false>(p, frag_row0(f + 1), nw0, lane);
-                        n2 = load_res_piece<2, 1, NF, false>(p, frag_row0(f + 1), nw0, lane);
-                    }
-                }
-                epilogue<1, NF, false, true, true, 16, GN>(p, *reinterpret_cast<f32x4(*)[1][NF]>(&acc[f]), m0f, nw0, 0, lane, estage, r0, r1, r2, res_pre, bv, true, &gn);
-                if constexpr (GN) {
-                    // writer = this wave tile's run of rows inside one statistics group; its slot is unique inside the group (gemm_common.h gn_flush)
+            // hand-managed epilogue (gemm_common.h e4_*): asm loads one fragment ahead, one wait per fragment
+            auto rowfn = [&](int f) __attribute__((always_inline)) -> long long { return frag_row0<HM>(q, f); };
+            auto flushfn = [&](int f, long long m0f, unsigned& slot) __attribute__((always_inline)) -> bool {
+                // writer = this wave tile's run of rows inside one statistics group; its slot is unique inside the group (gn_flush)
+                bool flush = f + 1 == MF;
+                slot = q.tslot;
+                if (HM == HM_CONV) {
                     const long long sid = m0f / p.gn_rps;
-                    bool flush = f + 1 == MF;
-                    unsigned slot;
-                    if (HM == HM_CONV) {
-                        flush = flush || (m0f + 16) / p.gn_rps != sid;
-                        const long long first = mw0 / p.gn_rps == sid ? mw0 - sid * p.gn_rps : 0;
-                        slot = (unsigned)((first + WM - 1) / WM);
-                    } else {
-                        // temporal tiles: the host only offers the statistics epilogue for the 3-D GroupNorm (gn_rps = T * S: the wave's 3 frames
-                        // x 32 positions lie in one group); writer index inside the sample = (frame block, position block, wave row)
-                        const int sb = tm % sblocks, tb = (tm / sblocks) % tblocks;
-                        slot = (unsigned)((tb * sblocks + sb) * 2 + wm);
-                    }
-                    if (flush) gn_flush<NF>(p, gn, sid, nw0, lane, estage, slot);
+                    flush = flush || (m0f + 16) / p.gn_rps != sid;
+                    const long long first = q.mw0 / p.gn_rps == sid ? q.mw0 - sid * p.gn_rps : 0;
+                    slot = (unsigned)((first + WM - 1) / WM);
                 }
-            });
+                return flush;
+            };
+            // (an opaque copy of the lane id: everything the epilogue derives from it is computed here, per tile - as loop invariants those values
+            // were hoisted in front of the main loop, spilled there, and re-read from scratch ~20 times per fragment)
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            e4_retire_tile<MF, NF, GN>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -498,6 +559,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
 int v3d_conv_halo_variant(const V3dGemmParams& p, int mode) {
     auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
     if (p.N % 320 || p.K % 32 || p.K * 2 > 65536 || p.out_fp32 || p.split_n > 1) return 0;
+    if (!e4_ok(p, 96, 80)) return 0;                                // the kernels only carry the hand-managed epilogue
     if (p.A2 && (p.K1 <= 0 || p.K1 >= p.K || p.K1 % 32 || p.lda2 % 8 || !al(p.A2, 16))) return 0;
     if (p.ldo % 8 || !al(p.out, 16)) return 0;
     if (p.add && (!al(p.add, 16) || p.add_ld % 4)) return 0;

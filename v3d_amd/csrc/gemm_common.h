@@ -518,4 +518,216 @@ __device__ __forceinline__ void v3_retire_chunks(const GP& p, f32x4 (&acc)[NCH *
     }
 }
 
+
+// =====================================================================================================================================
+// Hand-managed epilogue of the persistent kernels (round 3): same arithmetic as epilogue<> above for the branch-free case, but every
+// memory access the compiler would wrap in a wait is taken out of its hands.
+// Why: while LDS-DMA (buffer_load ... lds) is in flight hipcc answers every ordinary VGPR-destination load with s_waitcnt vmcnt(0) at its
+// first use and puts another in front of every ds_write to the LDS object the DMA targets.  In the epilogue that turned each of the ~10
+// loads / staging writes per 16-row fragment (per-image vector, residual pieces, blend coefficients, spilled scalars) into its own
+// full memory round trip - 60-90 serialised round trips per tile; rocprof / disassembly: three tile epilogues cost 90 of the 319 us of a
+// 64x64 convolution (profiles/r03_conv_ablation.txt), and the K = 320 linears (10 main-loop steps per tile) were mostly epilogue.
+// Here: loads are inline asm (the compiler neither counts nor waits for them), issued ONE FRAGMENT AHEAD of their use; staging writes are
+// inline asm; per fragment there is exactly one s_waitcnt vmcnt(0), placed after the fragment's arithmetic and before its stores, when
+// everything outstanding (the previous fragment's stores, the next fragment's loads) is at least a fragment's work old.  Per-row-group
+// constants (bias + per-image vector, blend coefficients) are loaded once per wave tile and again only when a fragment enters another row group.
+// Host contract (e4_ok): bf16 output, whole wave tiles, ldo % 8 == 0, out 16-B aligned; add 16-B aligned, add_ld % 4 == 0, add_rpg % 16 == 0;
+// res1 / res2 16-B aligned with row strides % 8 == 0; coef_rpg % 16 == 0.
+struct E4Res {
+    u32x4 a0, a1, a2;      // residual #1: 16-byte row pieces of one fragment (piece k of lane l = chunk k * 64 + l of the 16 x (NF * 2) chunk grid)
+};                         // (residual #2 - the alpha blend behind the 32x32 / 16x16 feed-forwards, 10 launches per evaluation - is fetched where it is used)
+template <int NF>
+struct E4Tile {
+    f32x4 ba[NF];          // bias + per-row-group vector of the lane's 4 channels per fragment column
+    float ca, c1, c2;
+    long long add_grp, coef_grp;
+};
+__device__ __forceinline__ u32x4 e4_load16(const void* ptr) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+__device__ __forceinline__ float e4_load4(const float* ptr) {
+    float r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+template <int NF>
+__device__ __forceinline__ void e4_load_res(const GP& p, long long m0f, long long nw0, int lane, E4Res& r) {
+    constexpr int CPRO = NF * 2, NP = 16 * CPRO;       // 16-byte chunks per row / per fragment
+    auto piece = [&](const bf16_t* base, long long ld, int k) __attribute__((always_inline)) -> u32x4 {
+        int c = k * 64 + lane;
+        if (NP % 64 != 0 && c >= NP) c = lane;                              // (lanes past the grid: any valid address, the value is never used)
+        return e4_load16(base + (m0f + c / CPRO) * ld + nw0 + (c % CPRO) * 8);
+    };
+    r.a0 = piece(p.res1, p.ldr1, 0);
+    r.a1 = piece(p.res1, p.ldr1, 1);
+    if constexpr (NP > 128) r.a2 = piece(p.res1, p.ldr1, 2);
+}
+__device__ __forceinline__ void e4_wait_res(E4Res& r) {          // everything outstanding has landed; names the destinations (asm loads: form (ii))
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.a2)::"memory");
+}
+// per-row-group constants of the wave tile's fragment starting at row m0f (synchronous: once per tile, and when a fragment enters another group)
+template <int NF>
+__device__ __forceinline__ void e4_tile_consts(const GP& p, long long m0f, long long nw0, int lane, E4Tile<NF>& t) {
+    const int nb = (int)nw0 + (lane >> 4) * 4;
+    f32x4 bv[NF], av[NF];
+    float cf0 = p.c_acc, cf1 = p.c_res1, cf2 = p.c_res2;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bv[j] = av[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) bv[j] = __builtin_bit_cast(f32x4, e4_load16(p.bias + nb + j * 16));
+    }
+    t.add_grp = p.add ? m0f / p.add_rpg : 0;
+    if (p.add) {
+        const float* av0 = p.add + t.add_grp * p.add_ld + nb;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) av[j] = __builtin_bit_cast(f32x4, e4_load16(av0 + j * 16));
+    }
+    t.coef_grp = p.coef ? m0f / p.coef_rpg : 0;
+    if (p.coef) {
+        const float* cf = p.coef + t.coef_grp * 3;
+        cf0 = e4_load4(cf);
+        cf1 = e4_load4(cf + 1);
+        cf2 = e4_load4(cf + 2);
+    }
+    // one wait for all of them (the statement names every destination: nothing above may be read, copied or spilled before it)
+    static_assert(NF == 4 || NF == 5, "e4: 64- or 80-channel wave tiles");
+    if constexpr (NF == 5)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]),
+                     "+v"(av[4]), "+v"(cf0), "+v"(cf1), "+v"(cf2)::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(cf0),
+                     "+v"(cf1), "+v"(cf2)::"memory");
+#pragma unroll
+    for (int j = 0; j < NF; ++j) t.ba[j] = bv[j] + av[j];
+    t.ca = cf0;
+    t.c1 = cf1;
+    t.c2 = cf2;
+}
+__device__ __forceinline__ void e4_lds_write16(unsigned addr, u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void e4_lds_write8(unsigned addr, uint32_t w0, uint32_t w1) {
+    const u32x2 v = {w0, w1};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// one 16-row fragment: acc (+ constants, residuals) -> bf16 -> staged rows -> 16-byte-per-lane row stores.  `cur` = this fragment's residual
+// pieces (landed), `nxt` = the next fragment's (in flight; waited for inside, before this fragment's stores).  Residual #1 goes through the
+// staging rows IN PLACE: its row pieces are written where the output rows will stand, every lane reads its own 8 bytes per fragment
+// column, adds, and writes the bf16 result back to the same 8 bytes (4 live floats per column instead of the whole fragment).
+template <int NF, bool GN>
+__device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long long m0f, long long nw0, int lane, unsigned char* stage, const E4Res& cur,
+                                            E4Res& nxt, const E4Tile<NF>& t, GnAcc<GN ? NF : 1>& gn) {
+    constexpr int CPRO = NF * 2, NP = 16 * CPRO, SROW = NF * 32 + 16;
+    const int fr = lane & 15, fq = (lane >> 4) * 4;
+    const unsigned sbase = lds_addr(stage);
+    auto piece_addr = [&](int k) __attribute__((always_inline)) -> unsigned {
+        const int c = k * 64 + lane;
+        return sbase + (unsigned)((c / CPRO) * SROW + (c % CPRO) * 16);
+    };
+    const int mine_off = fr * SROW + fq * 2;                               // the lane's 8 bytes of fragment column j sit at mine + j * 32
+    const unsigned mine = sbase + (unsigned)mine_off;
+    const bool has1 = p.res1 != nullptr, has2 = p.res2 != nullptr;
+    if (has1) {
+        e4_lds_write16(piece_addr(0), cur.a0);
+        e4_lds_write16(piece_addr(1), cur.a1);
+        if constexpr (NP > 128) {
+            if (NP % 64 == 0 || lane < NP - 128) e4_lds_write16(piece_addr(2), cur.a2);
+        }
+    }
+    // residual #2 (rare): the lane's 8 bytes per fragment column straight from memory (MFMA layout), fetched and waited for here
+    u32x2 q2[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) q2[j] = u32x2{0u, 0u};
+    if (has2) {
+        const bf16_t* r2 = p.res2 + (m0f + fr) * p.ldr2 + nw0 + fq;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(q2[j]) : "v"(r2 + j * 16) : "memory");
+        static_assert(NF == 4 || NF == 5, "e4: 64- or 80-channel wave tiles");
+        if constexpr (NF == 5)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]), "+v"(q2[4]), "+v"(nxt.a0), "+v"(nxt.a1), "+v"(nxt.a2)::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]), "+v"(nxt.a0), "+v"(nxt.a1), "+v"(nxt.a2)::"memory");
+    }
+    if (has1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (acc[j][r] + t.ba[j][r]) * t.ca;
+        if (has1) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(stage + mine_off + j * 32);
+            o[0] += t.c1 * bflo(rr.x); o[1] += t.c1 * bfhi(rr.x); o[2] += t.c1 * bflo(rr.y); o[3] += t.c1 * bfhi(rr.y);
+        }
+        if (has2) {
+            o[0] += t.c2 * bflo(q2[j][0]); o[1] += t.c2 * bfhi(q2[j][0]); o[2] += t.c2 * bflo(q2[j][1]); o[3] += t.c2 * bfhi(q2[j][1]);
+        }
+        const uint32_t w0 = pack2bf(o[0], o[1]), w1 = pack2bf(o[2], o[3]);
+        e4_lds_write8(mine + j * 32, w0, w1);
+        if constexpr (GN) {
+            gn_add_pair(gn.s[j][0], gn.q[j][0], w0);
+            gn_add_pair(gn.s[j][1], gn.q[j][1], w1);
+        }
+    }
+    // the one wait of the fragment: the previous fragment's stores and the next fragment's residual loads
+    e4_wait_res(nxt);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16_t* outz = reinterpret_cast<bf16_t*>(p.out) + m0f * p.ldo + nw0;
+#pragma unroll
+    for (int k = 0; k < (NP + 63) / 64; ++k) {
+        const int c = k * 64 + lane;
+        const int row = c / CPRO, ch = c % CPRO;
+        if (NP % 64 == 0 || c < NP) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
+    }
+}
+
+// retire the MF fragments of a finished wave tile; RowFn(f) = first output row of fragment f, FlushFn(f, m0f) = (flush?, slot) of the
+// GroupNorm-statistics epilogue.  Residual pieces travel by value (a reference went through a stack array, see conv.hip halo_retire).
+template <int F, int MF, int NF, bool GN, typename RowFn, typename FlushFn>
+__device__ __forceinline__ void e4_retire(const GP& p, f32x4 (&acc)[MF][NF], long long nw0, int lane, unsigned char* stage, E4Res cur, E4Tile<NF> t,
+                                          GnAcc<GN ? NF : 1>& gn, RowFn rowfn, FlushFn flushfn) {
+    if constexpr (F < MF) {
+        const long long m0f = rowfn(F);
+        E4Res nxt = cur;
+        if constexpr (F + 1 < MF) {
+            if (p.res1) e4_load_res<NF>(p, rowfn(F + 1), nw0, lane, nxt);
+        }
+        if ((p.add && m0f / p.add_rpg != t.add_grp) || (p.coef && m0f / p.coef_rpg != t.coef_grp)) {
+            e4_wait_res(nxt);                 // (rare: the wave tile straddles two row groups - the constants' wait below must not strand these)
+            e4_tile_consts<NF>(p, m0f, nw0, lane, t);
+        }
+        e4_fragment<NF, GN>(p, acc[F], m0f, nw0, lane, stage, cur, nxt, t, gn);
+        if constexpr (GN) {
+            unsigned slot = 0;
+            if (flushfn(F, m0f, slot)) gn_flush<NF>(p, gn, m0f / p.gn_rps, nw0, lane, stage, slot);
+        }
+        e4_retire<F + 1, MF, NF, GN>(p, acc, nw0, lane, stage, nxt, t, gn, rowfn, flushfn);
+    }
+}
+template <int MF, int NF, bool GN, typename RowFn, typename FlushFn>
+__device__ __forceinline__ void e4_retire_tile(const GP& p, f32x4 (&acc)[MF][NF], long long nw0, int lane, unsigned char* stage, RowFn rowfn, FlushFn flushfn) {
+    E4Res cur;
+    cur.a0 = cur.a1 = cur.a2 = u32x4{0u, 0u, 0u, 0u};
+    if (p.res1) e4_load_res<NF>(p, rowfn(0), nw0, lane, cur);
+    E4Tile<NF> t;
+    e4_tile_consts<NF>(p, rowfn(0), nw0, lane, t);          // (its vmcnt(0) also lands the residual pieces of fragment 0)
+    asm volatile("" : "+v"(cur.a0), "+v"(cur.a1), "+v"(cur.a2));
+    GnAcc<GN ? NF : 1> gn;
+    if constexpr (GN) gn_zero(gn);
+    e4_retire<0, MF, NF, GN>(p, acc, nw0, lane, stage, cur, t, gn, rowfn, flushfn);
+}
+
+// host: may a launch use the hand-managed epilogue? (wm x wn = wave tile)
+inline bool e4_ok(const V3dGemmParams& p, int wm, int wn) {
+    auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
+    if (p.out_fp32 || p.M % wm || p.N % wn || p.ldo % 8 || !al(p.out, 16)) return false;
+    if (p.bias && !al(p.bias, 16)) return false;
+    if (p.add && (!al(p.add, 16) || p.add_ld % 4 || p.add_rpg % 16)) return false;
+    if (p.res1 && (!al(p.res1, 16) || p.ldr1 % 8)) return false;
+    if (p.res2 && (!al(p.res2, 8) || p.ldr2 % 4)) return false;
+    if (p.coef && p.coef_rpg % 16) return false;
+    return true;
+}
+
 }  // namespace
