@@ -134,9 +134,14 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
             if fsd:
                 fcfg = cfg["model"]["params"]["first_stage_config"] if "model" in cfg else cfg["params"]["first_stage_config"]
                 ae_model = instantiate_from_config(fcfg).eval()
-                missing, unexpected = ae_model.load_state_dict(fsd, strict=False)
-                print(f"conditioning autoencoder restored from {ae_ckpt} ({len(missing)} missing / {len(unexpected)} unexpected keys)")
-                model._v3d_ae_model = ae_model = ae_model.to(device)
+                # strict, like the reference's `ae_model.load_state_dict(...)` (V3D_512.py:162): a wrong or truncated svd_xt file must not
+                # silently encode the conditioning view with partly random weights
+                ae_model.load_state_dict(fsd, strict=True)
+                print(f"conditioning autoencoder restored from {ae_ckpt} ({len(fsd)} tensors)")
+                ae_model = ae_model.to(device)
+                # cached OUTSIDE the module tree: a plain attribute assignment would register it as a submodule and put `_v3d_ae_model.*`
+                # keys into model.state_dict() / parameters() / .to()
+                object.__setattr__(model, "_v3d_ae_model", ae_model)
         if ae_model is None:
             ae_model = model.first_stage_model
             if checkpoint_path is not None:
@@ -151,7 +156,7 @@ def sample_one(input_path: str = "assets/test_image.png", checkpoint_path: Optio
         clip_model = getattr(model, "_v3d_clip_model", None)
         if clip_model is None:
             clip_model = load_clip_model(device, clip_checkpoint_path, synthetic, clip_config)
-            model._v3d_clip_model = clip_model
+            object.__setattr__(model, "_v3d_clip_model", clip_model)      # (outside the module tree, like the conditioning autoencoder)
         cond_frames_without_noise = clip_model(image.to(device).float())
     if cond_frames is None or cond_frames_without_noise is None:
         if not synthetic:

@@ -130,7 +130,9 @@ def test_two_ranks_on_one_gpu_hip_sharded_equals_unsharded(T, H, W, steps, split
     assert [r[1] for r in res] == split
     for rank, _, r_unet, r_dec, r_samp, sent in res:
         print(f"[sharded T={T} rank {rank}] unet rel/cos {r_unet}  decode {r_dec}  sampler({steps} steps) {r_samp}  sent {sent / 1e6:.1f} MB")
-        assert r_unet[0] <= 4e-2 and r_unet[1] >= 0.999, f"rank {rank}: sharded U-Net vs unsharded HIP: {r_unet}"
-        assert r_dec[0] <= 4e-2 and r_dec[1] >= 0.999, f"rank {rank}: sharded decode vs unsharded HIP: {r_dec}"
+        # (deterministic kernels since round 3: what is left is the other work decomposition - partial sums of the 3-D GroupNorm grouped per
+        # rank, other tile counts - i.e. rounding; rounds 1-2 could only bound this at the 4e-2 of a bf16-vs-fp32 comparison)
+        assert r_unet[0] <= 2e-2 and r_unet[1] >= 0.9995, f"rank {rank}: sharded U-Net vs unsharded HIP: {r_unet}"
+        assert r_dec[0] <= 2e-2 and r_dec[1] >= 0.9995, f"rank {rank}: sharded decode vs unsharded HIP: {r_dec}"
         assert r_samp[1] >= 0.995, f"rank {rank}: sharded sampler loop vs unsharded HIP: {r_samp}"
         assert sent > 0

@@ -3,6 +3,7 @@
 Tolerance: bf16 kernels vs fp32 reference: cosine >= 0.999 and max|err|/max|ref| <= 4e-2 for a full
 network evaluation (per-op bound 2e-2 is enforced in test_ops_gpu.py); sampler latents: cosine >= 0.99."""
 import pytest
+from conftest import record_parity
 import torch
 
 from conftest import rel_cos, full_inputs as _full_inputs  # noqa: F401  (`full_unet` is the session fixture of conftest.py)
@@ -118,8 +119,12 @@ def test_full_size_batch_independence(full_unet):
     both = full_unet(x, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi).float()
     half = full_unet(x[T:], ts[T:], context=ctx[T:], y=y[T:], num_video_frames=T, image_only_indicator=ioi[1:]).float()
     assert torch.isfinite(both).all()
+    again = full_unet(x, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi).float()
+    assert torch.equal(again, both), "two identical evaluations at the headline size differ: the engine is not deterministic"
     rel, cos = rel_cos(both[T:], half)
-    assert rel <= 2e-2 and cos >= 0.9995, (rel, cos)
+    record_parity("batch_independence_full_size", {"max_rel_err": round(rel, 6), "cosine": round(cos, 7)})
+    # (another work decomposition: other tile counts / kernel choices and other GroupNorm partial-sum groupings - rounding differences only)
+    assert rel <= 1e-2 and cos >= 0.9999, (rel, cos)
 
 
 def test_scene_config_batch_independence(full_unet):
@@ -135,7 +140,8 @@ def test_scene_config_batch_independence(full_unet):
     half = full_unet(x[T:], ts[T:], context=ctx[T:], y=y[T:], num_video_frames=T, image_only_indicator=ioi[1:]).float()
     assert both.shape == (2 * T, 4, H, W) and torch.isfinite(both).all()
     rel, cos = rel_cos(both[T:], half)
-    assert rel <= 2e-2 and cos >= 0.9995, (rel, cos)
+    record_parity("batch_independence_scene", {"max_rel_err": round(rel, 6), "cosine": round(cos, 7)})
+    assert rel <= 1e-2 and cos >= 0.9999, (rel, cos)
 
 
 def test_full_width_vs_oracle(full_unet):

@@ -1,9 +1,11 @@
 """-m gpu: parity of the product path AT the headline configuration (BASELINE.json configs[1]) and over the whole sampler
 loop, against the fp32 CPU oracle (oracle/sgm_oracle.py, pinned to the reference by tests/test_oracle_pinned.py).
 
-  * test_headline_unet_eval_vs_oracle      width 320, 36 images (cfg 2 x T 18), 64 x 64 latents: ONE denoiser evaluation of the
-                                           benchmark itself (3-D GroupNorm over 18 frames, 18-token temporal attention at 8192 x 5
-                                           problems, the persistent 147456-row GEMM tiles) vs the oracle.
+  * test_headline_rollout_3_steps_vs_oracle  width 320, 36 images (cfg 2 x T 18), 64 x 64 latents: a 3-step EulerEDM rollout of the
+                                           benchmark's own network, every denoiser call teacher-forced against the oracle (3-D GroupNorm
+                                           over 18 frames, 18-token temporal attention at 8192 x 5 problems, the persistent 147456-row
+                                           GEMM tiles) + the final latent.
+  * test_headline_decoder_T18_vs_oracle    the decode half at its own size: full-width VideoDecoder, T = 18, 64 x 64 -> 512 x 512.
   * test_rollout_25_steps_cosine_and_psnr  SURVEY.md 8d end-to-end bar at width 64: T = 18, 64 x 64 latents, 25 EulerEDM steps,
                                            LinearPredictionGuider 4.5, DiffusionEngine.decode_first_stage -> 512 x 512 frames:
                                            latent cosine >= 0.99 and decoded PSNR >= 35 dB; both numbers are printed and recorded.
@@ -35,24 +37,90 @@ torch.set_grad_enabled(False)
 DEV = "cuda"
 
 
-def test_headline_unet_eval_vs_oracle(full_unet):
+def test_headline_rollout_3_steps_vs_oracle(full_unet):
+    """BASELINE.json configs[1] sizes for the whole sampler stack: width 320, T = 18, 64 x 64 latents, cfg-doubled batch of 36 images,
+    3 EulerEDM steps x LinearPredictionGuider (4.5) x Denoiser x OpenAIWrapper on the HIP kernels.
+      (1) every denoiser call of the loop re-evaluated by the fp32 oracle ON THE HIP TRAJECTORY'S OWN INPUTS (teacher-forced: the
+          one-evaluation tolerance at the headline size, at three different noise levels - the first call is the single-evaluation
+          check rounds 1-2 recorded as `headline_unet_eval`);
+      (2) the final latent against the fp32 guider / Euler arithmetic applied to the ORACLE's outputs of those calls: what the rollout
+          would have produced had every evaluation been exact (the oracle's own 3-step trajectory would cost three more 2-minute
+          evaluations for the same information: the two differ only through the inputs of calls 2 and 3, which (1) already holds to
+          the per-call bound)."""
     from oracle import sgm_oracle as O
-    T = 18
-    x, ts, ctx, y = full_inputs(2 * T, 31)
-    ts = ts.abs() * 1.5 - 1.0                       # c_noise = ln(sigma) / 4 of the sigma schedule lies in [-1.6, 1.7]
-    ioi = torch.zeros(2, T)
-    out = full_unet(x.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi.to(DEV)).float().cpu()
+    from tiny import build_denoiser
+    from v3d_amd.sgm.modules.diffusionmodules import sampling
+    T, H, W, steps, scale = 18, 64, 64, 3, 4.5
+    P = "v3d_amd.sgm.modules.diffusionmodules."
+    sampler = sampling.EulerEDMSampler(discretization_config={"target": P + "discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+                                       num_steps=steps, guider_config={"target": P + "guiders.LinearPredictionGuider",
+                                                                       "params": {"max_scale": scale, "min_scale": scale, "num_frames": T}}, device=DEV)
+    den, wr = build_denoiser(), OpenAIWrapper(full_unet)
+    noise, c, uc = synth.synthetic_conditioning(T, H, W, seed=29)
+    extra = {"image_only_indicator": torch.zeros(2, T, device=DEV), "num_video_frames": T}
+    calls = []
+
+    def denoiser(i, s, cc):
+        out = den(wr, i, s, cc, **extra)
+        calls.append((i.detach().float().cpu().clone(), s.detach().float().cpu().clone(), {k: v.detach().float().cpu() for k, v in cc.items()},
+                      out.detach().float().cpu().clone()))
+        return out
+
+    z = sampler(denoiser, noise.clone().to(DEV), cond=to_dev(c, DEV), uc=to_dev(uc, DEV)).float().cpu()
+    assert len(calls) == steps and torch.isfinite(z).all()
     sd = {k: v.detach().float().cpu() for k, v in full_unet.state_dict().items()}
+    ucfg = synth.unet_config(320)
+    ioi = torch.zeros(2, T)
+    sigmas = O.edm_sigmas(steps, sigma_max=700.0)
+    gscale = O.guider_scale("linear", T, scale, scale)
+    x = noise.clone() * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    per_call, t0 = [], time.time()
+    for i, (inp, sig, cc, out) in enumerate(calls):
+        ref = O.denoise(lambda x8, cn, ctx, vec: O.unet_forward(sd, ucfg, x8, cn, ctx, vec, T, ioi), inp, sig, cc)
+        rel, cos = rel_cos(out, ref)
+        per_img = min(rel_cos(out[k], ref[k])[1] for k in range(2 * T))
+        per_call.append({"sigma": round(float(sig[0]), 4), "max_rel_err": round(rel, 5), "cosine": round(cos, 6), "min_per_image_cosine": round(per_img, 6)})
+        # the exact-evaluation trajectory: guider + Euler update in fp32 on the oracle's output
+        xu, xc = ref.chunk(2)
+        d = (x - (xu + gscale.reshape(-1, 1, 1, 1) * (xc - xu))) / sigmas[i]
+        x = x + (sigmas[i + 1] - sigmas[i]) * d
+    dt = time.time() - t0
+    rel_z, cos_z = rel_cos(z, x)
+    record_parity("headline_rollout_3_steps", {"images": 2 * T, "T": T, "width": 320, "latent": [H, W], "steps": steps, "cfg_scale": scale,
+                                               "per_call_teacher_forced": per_call, "final_latent_cosine": round(cos_z, 6),
+                                               "final_latent_max_rel_err": round(rel_z, 5), "oracle_seconds": round(dt, 1),
+                                               "oracle_threads": torch.get_num_threads()})
+    record_parity("headline_unet_eval", dict(per_call[0], images=2 * T, T=T, width=320, latent=[H, W], note="call 1 of headline_rollout_3_steps"))
+    for pc in per_call:
+        assert pc["max_rel_err"] <= 4e-2 and pc["cosine"] >= 0.999 and pc["min_per_image_cosine"] >= 0.998, per_call
+    # the guidance combination multiplies a per-evaluation error by up to 1 + 2 * 4.5: the latent bound is the sampler bar of SURVEY 8d
+    assert cos_z >= 0.999 and rel_z <= 0.1, (rel_z, cos_z)
+
+
+def test_headline_decoder_T18_vs_oracle():
+    """The decode half of the headline benchmark at its own size: full-width VideoDecoder (128 base channels), T = 18 frames,
+    64 x 64 latents -> 512 x 512 - the 3-D GroupNorm over 18 x 512^2 x 128 channels (6 x 10^8 elements per group: statistics in
+    slotted fp32 partials, added up in fp64) and the 18-frame temporal convolutions at 4.7 M rows - against the fp32 oracle."""
+    from oracle import sgm_oracle as O
+    from v3d_amd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
+    T = 18
+    with torch.device(DEV):
+        dec = VideoDecoder(**synth.decoder_config(128)).eval()
+    synth.init_module_fast(dec, seed=2)
+    z = torch.randn(T, 4, 64, 64, generator=torch.Generator().manual_seed(6))
+    out = dec(z.to(DEV), timesteps=T).float().cpu()
+    assert out.shape == (T, 3, 512, 512) and torch.isfinite(out).all()
+    again = dec(z.to(DEV), timesteps=T).float().cpu()
+    assert torch.equal(out, again), "two identical decodes differ: the decoder is not deterministic"
+    sd = {k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
     t0 = time.time()
-    ref = O.unet_forward(sd, synth.unet_config(320), x, ts, ctx, y, T, ioi)
+    ref = O.decoder_forward(sd, synth.decoder_config(128), z, T)
     dt = time.time() - t0
     rel, cos = rel_cos(out, ref)
-    per_frame = [rel_cos(out[i], ref[i])[1] for i in range(2 * T)]
-    record_parity("headline_unet_eval", {"images": 2 * T, "T": T, "width": 320, "latent": [64, 64], "cosine": round(cos, 6),
-                                         "max_rel_err": round(rel, 5), "min_per_image_cosine": round(min(per_frame), 6),
-                                         "oracle_seconds": round(dt, 1), "oracle_threads": torch.get_num_threads()})
+    db = psnr(out, ref)
+    record_parity("headline_decoder_T18", {"T": T, "latent": [64, 64], "frames": [512, 512], "vae_ch": 128, "cosine": round(cos, 6),
+                                           "max_rel_err": round(rel, 5), "psnr_db": round(db, 2), "oracle_seconds": round(dt, 1)})
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
-    assert min(per_frame) >= 0.998, per_frame
 
 
 def _engine(T, steps, scale, mc=64, vae_ch=32, **kw):
@@ -203,7 +271,7 @@ def test_decode_first_stage_chunked():
     assert rel_full > rel * 2                                                # ... and the product follows the chunked semantics
     out5 = eng.decode_first_stage(z.reshape(1, T, 4, 8, 8).to(DEV))          # "b t c h w" input form
     assert out5.shape == (1, T, 3, 64, 64)
-    assert rel_cos(out5[0], out)[0] <= 4e-2          # (two runs: GroupNorm partial sums meet in fp32 atomics, run-to-run bf16-ulp noise)
+    assert torch.equal(out5[0], out)                 # same work decomposition, no atomics anywhere (round 3): bit-equal
     record_parity("decode_first_stage_chunked", {"T": T, "chunk": 2, "max_rel_err": round(rel, 5), "cosine": round(cos, 6)})
     # encode_first_stage with chunking (video_diffusion.py:212-238); input_key != "latents" runs the VAE encoder + regulariser, whose
     # posterior sample draws torch.randn(mean.shape) on the CPU generator per chunk (distributions.py:37-41)
@@ -236,21 +304,19 @@ def test_graph_replay_matches_eager():
     args = (x8.to(DEV), ts.to(DEV), ctx.to(DEV), y.to(DEV))
     eager = ev(*args).float().clone()
     g = graphed(ev, enabled=True)
+    assert torch.equal(ev(*args).float(), eager), "two identical eager evaluations differ: the engine is not deterministic"
     for rep in range(3):
-        # not bit-equal: GroupNorm partial sums meet in fp32 atomics whose order varies run to run, and one bf16 ulp of a normalised
-        # activation walks through 50 layers (two eager runs differ by 1-2e-2 max rel, cosine 0.9998).  Stale partial sums (the bug this
-        # guards against: every GroupNorm sees 2x, 3x .. the sums) are an O(1) error.
-        rel, cos = rel_cos(g(*args), eager)
-        assert rel <= 4e-2 and cos >= 0.9995, f"graph replay {rep} differs from eager: rel {rel} cos {cos}"
+        # bit-equal (round 3): GroupNorm statistics are written one slot per writer with plain stores and added up in a fixed order, no
+        # kernel on the path uses floating-point atomics.  (Rounds 1-2: fp32 atomics, two eager runs differed by 1-2e-2 max rel and this
+        # test could only bound the replay at 4e-2.)  Stale partial sums (every GroupNorm seeing 2x, 3x .. the sums) are an O(1) error.
+        assert torch.equal(g(*args).float(), eager), f"graph replay {rep} differs from eager"
     # other inputs through the same captured graph
     args2 = tuple(a * 0.5 for a in args)
-    rel, cos = rel_cos(g(*args2), ev(*args2))
-    assert rel <= 4e-2 and cos >= 0.9995, (rel, cos)
+    assert torch.equal(g(*args2).float(), ev(*args2).float())
     # the decoder graph (3-D GroupNorm statistics spanning T frames)
     dec = build_decoder(DEV)
     z = decoder_latents(T, DEV)
     gd = graphed(lambda zz: dec(zz, timesteps=T), enabled=True)
     want = dec(z, timesteps=T).float().clone()
     for rep in range(3):
-        rel, cos = rel_cos(gd(z), want)
-        assert rel <= 4e-2 and cos >= 0.9995, f"decoder graph replay {rep} differs: rel {rel} cos {cos}"
+        assert torch.equal(gd(z).float(), want), f"decoder graph replay {rep} differs from eager"

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from tools.gpu_check import timeit
 from v3d_amd.hip import HipOps
-from v3d_amd.ops import GEMM_CONV3X3, GEMM_CONVT3, GN_SLOTS, GemmCall
+from v3d_amd.ops import GEMM_CONV3X3, GEMM_CONVT3, GemmCall, OpsBase
 hip = HipOps()
 dev, BF = "cuda", torch.bfloat16
 def run(name, n_img, H, W, K, N, mode, T=18):
@@ -19,7 +19,7 @@ def run(name, n_img, H, W, K, N, mode, T=18):
     kw = dict(Hin=H, Win=W, Hout=H, Wout=W, stride=1, up=1) if mode == GEMM_CONV3X3 else dict(T=T, S=S, tmin=0, tmax=T - 1)
     base = dict(A=A, W=Wt, out=out, M=M, N=N, K=K, mode=mode, res1=res, **kw)
     for rps, tag in ((S, "2-D"), (T * S, "3-D")):
-        st = torch.zeros(M // rps, GN_SLOTS, 32, 2, device=dev)
+        st = torch.zeros(M // rps, OpsBase.gn_nslots(rps, rps // S), 32, 2, device=dev)
         t0 = timeit(lambda: hip.gemm(GemmCall(**base)))
         t1 = timeit(lambda: hip.gemm(GemmCall(gn_stats=st, gn_rps=rps, gn_cpg=N // 32, **base)))
         t2 = timeit(lambda: hip.groupnorm_stats(out, None, st, n_img, S, 32, rps // S))

@@ -517,6 +517,24 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
         // ---------------- tile finished for this group: retire it while the other group keeps the MFMA pipe busy
         long long e_m0, e_n0;
         tile_origin(it, e_m0, e_n0);
+        if constexpr (!GEGLU && EMF == 1 && SPAD == 16) {
+            // hand-managed epilogue (gemm_common.h e4_*): asm loads one fragment ahead of their use, one wait per 16-row fragment.  The host only
+            // launches these kernels when e4_ok holds (whole wave tiles inside or outside the output, aligned operands, bf16 output).
+            const long long mw0 = e_m0 + wm * WM, nw0 = e_n0 + wn * WN;
+            if (mw0 < p.M && nw0 < p.N) {
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));          // (keeps what the epilogue derives from the lane id out of the loop-invariant set: no spills)
+                auto rowfn = [&](int f) __attribute__((always_inline)) -> long long { return mw0 + f * 16; };
+                auto flushfn = [&](int f, long long m0f, unsigned& slot) __attribute__((always_inline)) -> bool {
+                    // writer = this wave tile's run of rows inside one statistics group; its slot is unique inside the group (gn_flush)
+                    const long long sid = m0f / p.gn_rps;
+                    const long long first = mw0 / p.gn_rps == sid ? mw0 - sid * p.gn_rps : 0;
+                    slot = (unsigned)((first + WM - 1) / WM);
+                    return f + 1 == MF || (m0f + 16) / p.gn_rps != sid;
+                };
+                e4_retire_tile<MF, NF, GN>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
+            }
+        } else
         {
             const long long mw0 = e_m0 + wm * WM, nw0 = e_n0 + wn * WN;
             const bool inside = mw0 < p.M && nw0 < p.N;
@@ -868,7 +886,9 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
             fill_k = e ? atof(e) : 0.9;
         }
         const bool want = impl_choice() == 3 || fill3 >= fill_k * fill2;
-        if (want && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) return launch_v3<MODE, GEGLU>(p, st, variant);
+        // (non-GEGLU v3 kernels only carry the hand-managed epilogue: its operand contract on top of the tile-shape one)
+        const bool eok = GEGLU || (variant ? e4_ok(p, 96, 80) : e4_ok(p, 128, 64));
+        if (want && eok && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) return launch_v3<MODE, GEGLU>(p, st, variant);
     }
     if ((cfg_choice() == 5 || cfg_choice() == 6) && impl_choice() != 1 && p.N % 256 == 0 && p.K % 64 == 0 && p.K * 2 <= 65536) return launch256<MODE, GEGLU>(p, batch, st, cfg_choice());
     // N tile: 128 unless a 64-wide tile wastes less (e.g. N = 320: 5 x 64 exact vs 3 x 128 = 17 % padding)

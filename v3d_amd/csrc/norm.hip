@@ -128,45 +128,73 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 // which is all a consumer needs: v3d_groupnorm_apply, and the convolutions that normalise their input tile on its way into LDS
 // (v3d_gemm gn_in_table).  `sums` [n_stat][groups][2] fp64 is the frame-sharded runtime's hand-off: written when the slots are given,
 // read (after the all-reduce over ranks) when they are not.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, long long nslots, double* __restrict__ sums, int groups,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta, long long C,
-                                                          double inv_count, float eps, float* __restrict__ table) {
-    __shared__ double part[4][512];
-    __shared__ float ms[512];          // [group][2]: mean, rstd
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ stats, long long nslots, double* __restrict__ sums, int groups,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, long long C,
+                                                           double inv_count, float eps, float* __restrict__ table) {
+    // 1024 threads: 64 slot lanes x 16 float4 columns of a slot row (groups * 2 <= 64 floats); every lane adds its slots (stride 64) in fp64
+    // with 4 independent loads in flight, the lanes meet in LDS and are added in lane order - a fixed order whatever the scheduling.
+    // (The first version walked the slots with 4 lanes of 64 threads: 45 us per launch for the 1154 slots of a 64x64-level 3-D norm.)
+    __shared__ double part[64][64];
+    __shared__ double tot[64];
+    __shared__ float ms[64];           // [group][2]: mean, rstd
     const int tid = threadIdx.x;
     const long long st = blockIdx.x;
-    const int npair = groups * 2;      // <= 512
+    const int npair = groups * 2;      // <= 64, % 4 == 0 (host-checked)
+    const int vec = tid & 15, sl = tid >> 4;
     if (stats) {
-        for (int p0 = 0; p0 < npair; p0 += 64) {
-            const int pr = p0 + (tid & 63), sl = tid >> 6;
-            double a = 0.0;
-            if (pr < npair) {
-                const float* sp = stats + (st * nslots) * npair + pr;
-                for (long long k = sl; k < nslots; k += 4) a += (double)sp[k * npair];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (vec * 4 < npair) {
+            const float* sp = stats + (st * nslots) * npair + vec * 4;
+            long long k = sl;
+            for (; k + 192 < nslots; k += 256) {
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
+                const float4 v1 = *reinterpret_cast<const float4*>(sp + (k + 64) * npair);
+                const float4 v2 = *reinterpret_cast<const float4*>(sp + (k + 128) * npair);
+                const float4 v3 = *reinterpret_cast<const float4*>(sp + (k + 192) * npair);
+                a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+                a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+                a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+                a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
             }
-            if (pr < npair) part[sl][pr] = a;
+            for (; k < nslots; k += 64) {
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
+                a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
+            }
+        }
+        part[sl][vec * 4 + 0] = a0;
+        part[sl][vec * 4 + 1] = a1;
+        part[sl][vec * 4 + 2] = a2;
+        part[sl][vec * 4 + 3] = a3;
+        __syncthreads();
+        // the 64 lanes of a pair: a fixed binary tree (4 threads per pair add 16 lanes each in order, then ((0 + 1) + (2 + 3)))
+        if (tid < npair * 4) {
+            const int pr = tid >> 2, q = tid & 3;
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) a += part[q * 16 + l][pr];
+            part[q * 16][pr] = a;          // (only this thread reads rows q * 16 .. q * 16 + 15 of column pr)
         }
         __syncthreads();
-        for (int pr = tid; pr < npair; pr += 256) {
-            const double a = ((part[0][pr] + part[1][pr]) + part[2][pr]) + part[3][pr];
-            part[0][pr] = a;
-            if (sums) sums[st * npair + pr] = a;
+        if (tid < npair) {
+            const double a = (part[0][tid] + part[16][tid]) + (part[32][tid] + part[48][tid]);
+            tot[tid] = a;
+            if (sums) sums[st * npair + tid] = a;
         }
-    } else {
-        for (int pr = tid; pr < npair; pr += 256) part[0][pr] = sums[st * npair + pr];
+    } else if (tid < npair) {
+        tot[tid] = sums[st * npair + tid];
     }
     __syncthreads();
     if (!table) return;
-    for (int gidx = tid; gidx < groups; gidx += 256) {
-        const double mean = part[0][gidx * 2] * inv_count;
-        double var = part[0][gidx * 2 + 1] * inv_count - mean * mean;
+    if (tid < groups) {
+        const double mean = tot[tid * 2] * inv_count;
+        double var = tot[tid * 2 + 1] * inv_count - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        ms[gidx * 2] = (float)mean;
-        ms[gidx * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        ms[tid * 2] = (float)mean;
+        ms[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
     const int cpg = (int)(C / groups);
-    for (long long c = tid; c < C; c += 256) {
+    for (long long c = tid; c < C; c += 1024) {
         const int gidx = (int)(c / cpg);
         const float sc = gamma[c] * ms[gidx * 2 + 1];
         *reinterpret_cast<float2*>(table + (st * C + c) * 2) = make_float2(sc, beta[c] - ms[gidx * 2] * sc);
@@ -412,13 +440,14 @@ extern "C" int v3d_groupnorm_finalize(const float* stats, int64_t nslots, double
                                       v3d_stream_t stream) {
     V3D_REQUIRE(stats || sums, "v3d_groupnorm_finalize: neither slot statistics nor reduced sums given");
     V3D_REQUIRE(!stats || nslots > 0, "v3d_groupnorm_finalize: nslots must be > 0");
-    V3D_REQUIRE(n_stat > 0 && n_stat < (1ll << 31) && groups > 0 && groups <= 256, "v3d_groupnorm_finalize: bad n_stat / groups");
+    V3D_REQUIRE(n_stat > 0 && n_stat < (1ll << 31) && groups > 0 && groups <= 32 && groups % 2 == 0, "v3d_groupnorm_finalize: bad n_stat / groups (even, <= 32)");
+    V3D_REQUIRE(!stats || ((uintptr_t)stats & 15) == 0, "v3d_groupnorm_finalize: stats must be 16-byte aligned");
     V3D_REQUIRE(table || (stats && sums), "v3d_groupnorm_finalize: nothing to write");
     if (table) {
         V3D_REQUIRE(gamma && beta && C > 0 && C % groups == 0 && count > 0, "v3d_groupnorm_finalize: table needs gamma, beta, C %% groups == 0, count > 0");
         V3D_REQUIRE(((uintptr_t)table & 7) == 0, "v3d_groupnorm_finalize: table must be 8-byte aligned");
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)n_stat), dim3(256), 0, (hipStream_t)stream, stats, (long long)nslots, sums, groups, gamma,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)n_stat), dim3(1024), 0, (hipStream_t)stream, stats, (long long)nslots, sums, groups, gamma,
                        beta, (long long)C, count > 0 ? 1.0 / count : 0.0, eps, table);
     return v3d_check_launch("v3d_groupnorm_finalize");
 }

@@ -54,6 +54,15 @@ def run_decoder(pk: VAEPack, z: torch.Tensor, T: int, shard=None) -> torch.Tenso
     if shard is None:
         from ..dist import active_shard
         shard = active_shard()
+    if shard is not None:
+        # frame-sharded decode: `z` holds this rank's frames of every sample and the time axis the kernels see is the LOCAL one, whatever
+        # the caller passed (run_unet does the same).  A caller that chunks the decode (DiffusionEngine.decode_first_stage with
+        # en_and_decode_n_samples_a_time < frames) would hand over chunks that are not whole local samples - every rank would then run a
+        # different number of collectives: refuse instead of hanging or writing out of bounds.
+        if n % shard.T_local != 0:
+            raise ValueError(f"frame-sharded decode: {n} latent frames is not a multiple of this rank's {shard.T_local} frames "
+                             "(chunked decode_first_stage is not defined under a FrameShard: decode all local frames in one call)")
+        T = shard.T_local
     assert n % T == 0, f"{n} latent frames is not a multiple of timesteps={T}"
     env = Env(ops=ops, shard=shard)
     g = Geo(n=n, B=n // T, T=T, H=H, W=W)

@@ -213,6 +213,8 @@ class OpsBase:
                                          stats_hook=stats_hook, count_imgs=count_imgs, stats=stats)
         if out is None:
             out = self.empty((n_img * S, C), self.act_dtype, x1.device)
+        if tuple(out.shape) != (n_img * S, C):
+            raise ValueError(f"groupnorm: out has shape {tuple(out.shape)}, the normalised tensor is [{n_img * S}, {C}]")
         self.groupnorm_apply(x1, x2, table, out, n_img, S, imgs_per_stat, silu)
         return out
 
