@@ -44,6 +44,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_FP8_TFLOPS = 5000.0       # dense fp8 MFMA peak (the scene workload's e4m3 attention kernel is priced against this one)
 PEAK_HBM_GBPS = 8000.0
 RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)      # 312.5: launches below it are HBM-bound (classified per launch)
 F_UNET_TFLOP = 45.677          # algorithmic FLOPs of one denoiser evaluation (reference graph, cfg batch 36)
@@ -85,11 +86,11 @@ def build_models(device, width=320, vae_ch=128, steps=STEPS, cfg=CFG, frames=T_F
     return unet, OpenAIWrapper(unet), dec, sampler, denoiser
 
 
-def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False, frames=T_FRAMES):
+def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False, frames=T_FRAMES, inputs=1):
     """One sample = 25 guided network evaluations + the 18-frame decode.  With `graph` the network evaluation and the
     decode are captured once (first call) into HIP graphs and replayed (v3d_amd/engine/graph.py)."""
     from v3d_amd.engine.graph import graphed
-    extra = {"image_only_indicator": torch.zeros(2, frames, device=device), "num_video_frames": frames}
+    extra = {"image_only_indicator": torch.zeros(2 * inputs, frames, device=device), "num_video_frames": frames}
 
     def den(inp, sigma, cc):
         return denoiser(wrapped, inp, sigma, cc, **extra)
@@ -108,7 +109,7 @@ def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False
     return step
 
 
-def make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise, c, uc):
+def make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise, c, uc, B=1):
     """One sample with its frames sharded over the ranks for the whole path (v3d_amd/dist.py::sharded_sample): returns the gathered
     [18, 3, 512, 512] frames on every rank."""
     from v3d_amd.dist import sharded_sample
@@ -117,7 +118,7 @@ def make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise, c, uc):
         return dec(z * (1.0 / 0.18215), timesteps=shard.T_local)
 
     def step():
-        return sharded_sample(shard, sampler, denoiser, wrapped, decode, noise.clone(), c, uc, B=1)
+        return sharded_sample(shard, sampler, denoiser, wrapped, decode, noise.clone(), c, uc, B=B)
 
     return step
 
@@ -385,8 +386,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--shard", choices=["replica", "frames"], default="replica",
-                    help="multi-GPU mode: independent samples per rank (weak scaling, default) or ONE sample with its frames sharded over the ranks")
+    ap.add_argument("--shard", choices=["replica", "frames", "hybrid"], default="replica",
+                    help="multi-GPU mode: independent samples per rank (weak scaling, default), ONE sample with its frames sharded over the ranks, "
+                         "or cfg-parallel x frame-shard (2 x N/2: the unconditional / conditional halves on two frame groups)")
+    ap.add_argument("--workload", choices=["v3d512", "scene"], default="v3d512",
+                    help="v3d512 = BASELINE.json configs[1] (the headline: 18 frames, 64 x 64 latents); scene = configs[4] (24 frames, 576 x 1024 -> "
+                         "72 x 128 latents; --fp8 switches its spatial self-attention to the e4m3 MFMA kernel).  A scene line is never the headline number.")
+    ap.add_argument("--fp8", action="store_true", help="scene workload: fp8 (OCP e4m3) spatial self-attention (V3D_ATTN_FP8=1)")
+    ap.add_argument("--inputs", type=int, default=1, help="inputs per sample step (BASELINE.json configs[3]: batch-of-4 inputs); frames per step = inputs x frames")
+    ap.add_argument("--edm-steps", dest="edm_steps", type=int, default=STEPS, help="EDM sampler steps (configs[3]: 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-rollout", action="store_true")
@@ -412,18 +420,26 @@ def main():
     from v3d_amd import synth
     from v3d_amd.ops import get_ops
     assert get_ops().name == "hip"
-    unet, wrapped, dec, sampler, denoiser = build_models(device)
-    shard_mode = args.shard == "frames" and world > 1
+    scene = args.workload == "scene"
+    if args.fp8:
+        if not scene:
+            raise SystemExit("--fp8 belongs to --workload scene (BASELINE.json configs[4]); the headline config is bf16")
+        os.environ["V3D_ATTN_FP8"] = "1"
+    T_FR, LH, LW = (24, 72, 128) if scene else (T_FRAMES, LAT, LAT)
+    B_IN, E_STEPS = args.inputs, args.edm_steps
+    headline = not scene and B_IN == 1 and E_STEPS == STEPS          # roofline / cpu_baseline / parity legs belong to the headline workload
+    unet, wrapped, dec, sampler, denoiser = build_models(device, steps=E_STEPS, frames=T_FR)
+    shard_mode = args.shard in ("frames", "hybrid") and world > 1
     # replica mode: every rank generates its own sample (different seed per rank); frame-shard mode: ONE sample, same inputs everywhere
-    noise, c, uc = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23 + (0 if shard_mode else rank), device=device)
+    noise, c, uc = synth.synthetic_conditioning(T_FR, LH, LW, seed=23 + (0 if shard_mode else rank), device=device, batch=B_IN)
     shard = None
     if world > 1:
-        from v3d_amd.dist import FrameShard
-        shard = FrameShard(T_FRAMES)
+        from v3d_amd.dist import FrameShard, HybridShard
+        shard = HybridShard(T_FR) if args.shard == "hybrid" else FrameShard(T_FR)
     if shard_mode:
-        step = make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise, c, uc)
+        step = make_sharded_step(shard, wrapped, dec, sampler, denoiser, noise, c, uc, B=B_IN)
     else:
-        step = make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=args.graph)
+        step = make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=args.graph, frames=T_FR, inputs=B_IN)
 
     def barrier():
         if world > 1:
@@ -445,38 +461,68 @@ def main():
             dt = float(t.item())
         return out, dt
 
+    if shard is not None:
+        shard.bytes_sent = shard.n_exchanges = shard.n_allreduce = 0
     out, dt = timed(step, args.warmup, args.steps)
-    assert out.shape == (T_FRAMES, 3, LAT * 8, LAT * 8) and torch.isfinite(out).all()
+    assert out.shape == (B_IN * T_FR, 3, LH * 8, LW * 8) and torch.isfinite(out).all()
 
     result = None
     samples = args.steps * (1 if shard_mode else world)
     if rank == 0:
-        frames = samples * T_FRAMES
-        sample_tflop = STEPS * F_UNET_TFLOP + T_FRAMES * F_VAE_TFLOP_PER_FRAME
+        frames = samples * B_IN * T_FR
         par = f"frame-shard {shard.describe()}" if shard_mode else f"replica x{world}"
+        if scene:
+            wl = (f"BASELINE.json configs[4] shape: sparse-view scene config, random-init SVD-XT weights, {B_IN}x{T_FR}x4x{LH}x{LW} latent ({8 * LH}x{8 * LW} "
+                  f"frames), {E_STEPS} EulerEDM steps, cfg 4.5, {T_FR}-frame VideoDecoder decode, spatial self-attention "
+                  + ("fp8 e4m3 MFMA (V3D_ATTN_FP8=1)" if args.fp8 else "bf16") + " - NOT the headline workload")
+        else:
+            wl = (f"BASELINE.json configs[{1 if headline else 3}]: V3D_512 random-init SVD-XT weights, {B_IN}x{T_FR}x4x{LH}x{LW} latent, {E_STEPS} EulerEDM steps, "
+                  f"cfg 4.5 (LinearPredictionGuider), {T_FR}-frame VideoDecoder decode to 512x512"
+                  + (f", batch of {B_IN} inputs per step" if B_IN > 1 else "") + ", "
+                  + ("ONE sample, frames sharded over the GPUs (configs[2]/[3])" if shard_mode else "one sample per GPU"))
         result = {
-            "metric": "multi-view frames/sec, V3D_512 18-frame 25-step EDM", "value": round(frames / dt, 4), "unit": "frames/s",
+            "metric": "multi-view frames/sec, V3D_512 18-frame 25-step EDM" if headline else
+                      f"multi-view frames/sec, {'scene 24-frame' if scene else 'V3D_512 18-frame'} {E_STEPS}-step EDM, {B_IN} input(s) per step",
+            "value": round(frames / dt, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: V3D_512 random-init SVD-XT weights, 1x18x4x64x64 latent, 25 EulerEDM steps, "
-                                   "cfg 4.5 (LinearPredictionGuider), 18-frame VideoDecoder decode to 512x512, "
-                                   + ("ONE sample, frames sharded over the GPUs (configs[2]/[3])" if shard_mode else "one sample per GPU"),
-                       "frames": T_FRAMES, "edm_steps": STEPS, "latent": [T_FRAMES, 4, LAT, LAT], "parallelism": par},
-            "achieved_tflops_reference_graph": round(samples * sample_tflop / dt, 1),
-            "frac_of_bf16_peak_reference_graph": round(samples * sample_tflop / dt / PEAK_BF16_TFLOPS / world, 4),
+            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None,
+            "dtype": "bf16 (fp8 e4m3 spatial attention)" if args.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": wl, "frames": T_FR, "inputs_per_step": B_IN, "edm_steps": E_STEPS, "latent": [B_IN * T_FR, 4, LH, LW], "parallelism": par},
         }
-    if rank == 0 and not args.no_roofline:
+        if headline:
+            sample_tflop = STEPS * F_UNET_TFLOP + T_FRAMES * F_VAE_TFLOP_PER_FRAME
+            result["achieved_tflops_reference_graph"] = round(samples * sample_tflop / dt, 1)
+            result["frac_of_bf16_peak_reference_graph"] = round(samples * sample_tflop / dt / PEAK_BF16_TFLOPS / world, 4)
+        if shard_mode:
+            n_eval = (args.steps + args.warmup) * E_STEPS
+            cnt = shard.counters()
+            result["frame_shard_exchanges"] = {
+                "grouped_p2p_calls_per_evaluation_rank0": round(cnt["grouped_p2p_calls"] / n_eval, 1), "all_reduces_per_evaluation": cnt["all_reduces"] / n_eval,
+                "sent_MB_per_sample_rank0": round(cnt["bytes_sent"] / (args.steps + args.warmup) / 1e6, 1),
+                "note": "one grouped point-to-point launch per temporal norm + conv (raw halo + fp64 statistics) and per temporal attention (K|V); "
+                        "NO RCCL timing of this path existed before this run: the build boxes have one GPU"}
+    if rank == 0 and not args.no_roofline and headline:
         # per-launch HIP events need the launches to come from Python: the instrumented sample runs un-captured (and un-sharded)
         noise0, c0, uc0 = synth.synthetic_conditioning(T_FRAMES, LAT, LAT, seed=23, device=device)
         result["roofline"] = measure_rooflines(make_step(wrapped, dec, sampler, denoiser, noise0, c0, uc0, device, graph=False))
         result["config"]["hip_graph"] = bool(args.graph)
+    elif rank == 0 and not args.no_roofline:
+        # other workloads: the same live per-op-family table (its own bounds); the fp8 attention family is priced against the fp8 MFMA peak
+        noise0, c0, uc0 = synth.synthetic_conditioning(T_FR, LH, LW, seed=23, device=device, batch=B_IN)
+        rl = measure_rooflines(make_step(wrapped, dec, sampler, denoiser, noise0, c0, uc0, device, graph=False, frames=T_FR, inputs=B_IN))
+        for k in rl["per_kernel"]:
+            if k["kernel"] == "attn_spatial_fp8":
+                k["frac"] = round(k["achieved"] / PEAK_FP8_TFLOPS, 4)
+                k["peak"] = PEAK_FP8_TFLOPS
+        rl.pop("traffic", None); rl.pop("traffic_profile", None); rl.pop("traffic_unit", None)
+        result["roofline"] = rl
     if world > 1:
         dist.barrier()
     # ---- N > 1, replica mode: the frame-sharded (latency) mode of the same job, measured LAST and under a watchdog: it is a secondary
     #      number and its exchanges (grouped RCCL P2P between all ranks) must never cost the run its replica result - if it has not
     #      finished in time, rank 0 prints the line it has and every rank leaves without waiting for the others ----
     printed = [False]
-    if world > 1 and not shard_mode:
+    if world > 1 and not shard_mode and headline:
         import threading
 
         def bail():
@@ -513,7 +559,7 @@ def main():
         finally:
             watchdog.cancel()
         return
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:
         try:
             result["cpu_baseline"] = cpu_baseline(unet, dec)
         except Exception as e:  # the baseline is informational; never lose the GPU number to a host-side failure

@@ -62,7 +62,7 @@ def _gn_producer(ops, n_stat, rps, cout, device, groups=32, level=1, imgs_per_st
 _CONV_GN = os.environ.get("V3D_CONV_GN", "1") not in ("", "0")
 
 
-def conv3x3_gn(ops, x1, x2, norm, w, bias, g: "Geo", *, stats=None, **epi):
+def conv3x3_gn(ops, x1, x2, norm, w, bias, g: "Geo", *, stats=None, out=None, **epi):
     """conv3x3(SiLU(GroupNorm(x1 | x2))): openaimodel.py:267-271 (in_layers) / 302-314 (out_layers), 2-D norm (one statistics group per image)."""
     ga, be, eps = norm
     n, S = g.n, g.S
@@ -70,17 +70,18 @@ def conv3x3_gn(ops, x1, x2, norm, w, bias, g: "Geo", *, stats=None, **epi):
     N = w.shape[-2]
     K = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
     if _CONV_GN:
-        out = ops.empty((n * S, N), ops.act_dtype, x1.device)
+        if out is None:
+            out = ops.empty((n * S, N), ops.act_dtype, x1.device)
         call = GemmCall(A=x1, A2=x2, W=w, out=out, M=n * S, N=N, K=K, bias=bias, mode=GEMM_CONV3X3, Hin=g.H, Win=g.W, Hout=g.H, Wout=g.W,
                         gn_in=table, gn_in_rps=S, gn_in_silu=True, **epi)
         if ops.gemm_gn_in_supported(call):
             ops.gemm(call)
             return out
     h = ops.groupnorm(x1, x2, ga, be, n, S, eps=eps, silu=True, table=table)
-    return ops.conv3x3(h, w, bias, n, g.H, g.W, **epi)
+    return ops.conv3x3(h, w, bias, n, g.H, g.W, out=out, **epi)
 
 
-def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[torch.Tensor], *, eps_override=None, out_stats_imgs=0):
+def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[torch.Tensor], *, eps_override=None, out_stats_imgs=0, out=None):
     """2-D ResBlock (openaimodel.py:338-364 / model.py:131-151) on channels-last input (x1 [| x2] concatenated
     on channels but never materialised).  Returns xs [n*S, cout]; with out_stats_imgs = k > 0 also the GroupNorm partial sums of xs over
     groups of k images (the 3-D norm of the time_stack that follows), gathered by the last convolution: (xs, stats)."""
@@ -103,9 +104,9 @@ def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[tor
             skip = ops.linear(x1, p.skip_w[:, :c1], p.skip_b)
             skip = ops.linear(x2, p.skip_w[:, c1:], None, res1=skip)
     if not out_stats_imgs:
-        return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip)
+        return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip, out=out)
     st, gkw = _gn_producer(ops, g.n // out_stats_imgs, out_stats_imgs * S, p.w2.shape[-2], x1.device, imgs_per_stat=out_stats_imgs)
-    return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip, **gkw), st
+    return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip, out=out, **gkw), st
 
 
 def convt3_gn(ops, x, norm, w, bias, g: "Geo", *, stats=None, **epi):
@@ -144,26 +145,48 @@ def res_temporal(env: Env, g: Geo, p: ResPack, xs: torch.Tensor, *, coef=None, c
     if sh is None:
         h = convt3_gn(ops, xs, p.t_gn1, p.t_w1, p.t_b1, g, stats=xs_stats, **epi1, **gkw)
         return convt3_gn(ops, h, p.t_gn2, p.t_w2, p.t_b2, g, stats=st2, **epi2)
-    # frame-sharded: the statistics are all-reduced over ranks, GroupNorm writes the local frames straight into the middle of the split-halo
-    # buffer the 3-tap GEMM reads, the +-1 frames come from the neighbours
-    gn_kw = dict(imgs_per_stat=T, stats_hook=sh.allreduce_stats, count_imgs=sh.T_global)
-    buf, mid = sh.halo_buffer(g.B, S, C, ops.act_dtype, xs.device)
-    ga, be, eps = p.t_gn1
-    h = ops.groupnorm(xs, None, ga, be, g.n, S, eps=eps, silu=True, out=mid, stats=xs_stats, **gn_kw)
-    h = sh.convt3(ops, buf, p.t_w1, p.t_b1, g, **epi1, **gkw)
-    ga, be, eps = p.t_gn2
-    h = ops.groupnorm(h, None, ga, be, g.n, S, eps=eps, silu=True, out=mid, stats=st2, **gn_kw)
-    return sh.convt3(ops, buf, p.t_w2, p.t_b2, g, **epi2)
+    # frame-sharded (dist.py): `xs` already stands in the middle of split-halo buffer 0 (res_spatial wrote it there).  Per norm +
+    # convolution ONE grouped point-to-point call carries the RAW +-1 frame halos to the neighbours and this rank's fp64 (sum, sumsq)
+    # table to every rank; the normalisation of the local frames and of the received halo frames then uses the all-rank statistics.
+    B, Tl = g.B, sh.T_local
+    buf0, mid0 = sh.halo_buffer(B, S, C, ops.act_dtype, xs.device, slot=0)
+    buf1, mid1 = sh.halo_buffer(B, S, C, ops.act_dtype, xs.device, slot=1)
+    buf2, mid2 = sh.halo_buffer(B, S, C, ops.act_dtype, xs.device, slot=2)
+    if xs.data_ptr() != mid0.data_ptr():
+        mid0.copy_(xs)                        # (callers that could not produce into the buffer)
+        xs = mid0
+
+    def normalise(raw_buf, raw_mid, norm, stats):
+        ga, be, eps = norm
+        table = ops.groupnorm_table(raw_mid, None, ga, be, g.n, S, eps=eps, imgs_per_stat=Tl, count_imgs=sh.T_global, stats=stats,
+                                    stats_hook=lambda sums: sh.exchange_halo_and_sums(raw_buf, B, S, sums)[1])
+        ops.groupnorm_apply(raw_mid, None, table, mid1, g.n, S, Tl, True)
+        if not sh.first:                      # the neighbours' frames: one "image" per sample, normalised with that sample's table row
+            ops.groupnorm_apply(raw_buf[:B * S], None, table, buf1[:B * S], B, S, 1, True)
+        if not sh.last:
+            ops.groupnorm_apply(raw_buf[(B + B * Tl) * S:], None, table, buf1[(B + B * Tl) * S:], B, S, 1, True)
+
+    normalise(buf0, mid0, p.t_gn1, xs_stats)
+    sh.convt3(ops, buf1, p.t_w1, p.t_b1, g, out=mid2, **epi1, **gkw)
+    normalise(buf2, mid2, p.t_gn2, st2)
+    return sh.convt3(ops, buf1, p.t_w2, p.t_b2, g, **epi2)
+
+
+def _shard_out(env: Env, g: Geo, p: ResPack, dev):
+    """Frame-sharded runs: the spatial half of a VideoResBlock produces straight into the middle of split-halo buffer 0."""
+    if env.shard is None:
+        return None
+    return env.shard.halo_buffer(g.B, g.S, p.w2.shape[-2], env.ops.act_dtype, dev, slot=0)[1]
 
 
 def unet_resblock(env: Env, g: Geo, p: ResPack, x1, x2=None):
     """VideoResBlock of the U-Net: alpha * spatial + (1 - alpha) * temporal  (util.py:341-369)."""
-    xs, st = res_spatial(env, g, p, x1, x2, out_stats_imgs=g.T)
+    xs, st = res_spatial(env, g, p, x1, x2, out_stats_imgs=g.T, out=_shard_out(env, g, p, x1.device))
     return res_temporal(env, g, p, xs, coef=env.coefs[p.mixer], xs_stats=st)
 
 
 def vae_resblock(env: Env, g: Geo, p: ResPack, x):
     """VideoResBlock of the VAE decoder: alpha * temporal + (1 - alpha) * spatial (temporal_ae.py:79-80 - the
     opposite convention), i.e. xs + alpha * (time_stack residual)."""
-    xs, st = res_spatial(env, g, p, x, None, out_stats_imgs=g.T)
+    xs, st = res_spatial(env, g, p, x, None, out_stats_imgs=g.T, out=_shard_out(env, g, p, x.device))
     return res_temporal(env, g, p, xs, c_acc=p.alpha, xs_stats=st)
