@@ -24,6 +24,7 @@ def _flat_from(t: torch.Tensor) -> torch.Tensor:
 
 class EmulOps(OpsBase):
     name = "emul"
+    always_fuse = True      # the engine's "does the fused kernel pay here" policies are about GPU tile counts; the emulator takes every fused path (host-wiring coverage)
 
     def __init__(self, device="cpu", exact: bool = False):
         """exact=True keeps activations / packed weights in fp32 (no bf16 rounding points): the engine's wiring can then be

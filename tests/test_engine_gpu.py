@@ -105,6 +105,22 @@ def test_scene_shape_vs_oracle():
     rel, cos = rel_cos(out, ref)
     record_parity("scene_shape_unet_eval_width64", {"T": T, "latent": [H, W], "images": n, "max_rel_err": round(rel, 5), "cosine": round(cos, 6)})
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
+    # the same evaluation with the fp8 (OCP e4m3) spatial self-attention BASELINE.json configs[4] names (V3D_ATTN_FP8=1: tile-scaled q | k,
+    # slab-scaled V^T, P requantised in registers) - a NETWORK-level check against the fp32 oracle.  Stated tolerance of the scene config:
+    # cosine >= 0.998 and max rel <= 8e-2 (e4m3 has 3 mantissa bits: 6 % per element, averaged down by the 64-wide dot products and the
+    # residual stream; the bf16 path above holds 0.999 / 4e-2), and the fp8 result must stay close to the bf16 one.
+    import os
+    os.environ["V3D_ATTN_FP8"] = "1"
+    try:
+        out8 = net(x8.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi.to(DEV)).float().cpu()
+    finally:
+        os.environ["V3D_ATTN_FP8"] = "0"
+    rel8, cos8 = rel_cos(out8, ref)
+    relb, cosb = rel_cos(out8, out)
+    record_parity("scene_shape_unet_eval_width64_fp8_attention", {"max_rel_err": round(rel8, 5), "cosine": round(cos8, 6), "vs_bf16_max_rel": round(relb, 5),
+                                                                  "vs_bf16_cosine": round(cosb, 6)})
+    assert not torch.equal(out8, out), "V3D_ATTN_FP8=1 did not change the evaluation: the fp8 attention path was not taken"
+    assert rel8 <= 8e-2 and cos8 >= 0.998, (rel8, cos8)
 
 
 # ---- BASELINE.json configs[1] sizes (width 320, 64 x 64 latents, 18 frames, cfg-doubled) --------------------------------------

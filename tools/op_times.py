@@ -22,11 +22,15 @@ def wrap(name, keyfn):
     setattr(ops, name, f)
 def gk(g):
     taps = {0: 1, 1: 9, 2: 3}[g.mode]
-    ep = ("G" if g.geglu else "") + ("b" if g.bias is not None else "") + ("a" if g.add is not None else "") + ("r" if g.res1 is not None else "") + ("R" if g.res2 is not None else "") + ("c" if g.coef is not None else "") + ("f" if g.out.dtype == torch.float32 else "")
+    ep = ("N" if g.gn_in is not None else "") + ("S" if g.gn_stats is not None else "") + ("G" if g.geglu else "") + ("b" if g.bias is not None else "") + ("a" if g.add is not None else "") + ("r" if g.res1 is not None else "") + ("R" if g.res2 is not None else "") + ("c" if g.coef is not None else "") + ("f" if g.out.dtype == torch.float32 else "")
     return f"gemm m{g.mode} M={g.M} N={g.N} K={g.K} b={g.batch} [{ep}]", 2.0 * g.M * g.N * g.K * taps * g.batch
 wrap("gemm", gk)
 wrap("groupnorm_stats", lambda x1, x2, st, n, S, g, ips: (f"gn_stats n={n} S={S} C={x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)} ips={ips}", 0))
 wrap("groupnorm_apply", lambda x1, x2, *a: (f"gn_apply rows={x1.shape[0]} C={x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)}", 0))
+wrap("groupnorm_finalize", lambda st, sums, *a: (f"gn_finalize n_stat={st.shape[0]} slots={st.shape[1]}", 0))
+for nm in ("ff_fused", "ln_ff_fused", "ln_proj"):
+    if hasattr(ops, nm):
+        wrap(nm, (lambda nm_: lambda *a, **k: (f"{nm_} rows={a[0].shape[0]}", 0))(nm))
 wrap("layernorm", lambda x, *a, **k: (f"ln rows={x.shape[0]} C={x.shape[-1]} add={'add' in k}", 0))
 wrap("attn_spatial", lambda q, k, vT, out, n, S, h, sc: (f"attn_spatial n={n} S={S} h={h}", 4.0 * n * h * S * S * 64))
 wrap("attn_temporal", lambda q, k, v, out, h, sc: (f"attn_temporal {tuple(q.shape)}", 0))

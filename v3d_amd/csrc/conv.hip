@@ -580,12 +580,6 @@ int v3d_conv_halo_variant(const V3dGemmParams& p, int mode) {
     }
     if (mode == V3D_GEMM_CONVT3) {
         if (p.T % 6 || p.S % 32 || p.M % ((long long)p.T * p.S)) return 0;
-        // 3 taps per chunk leave the normalisation chain two steps of MFMA slots: it only pays where the 192 x 320 tiles fill the CUs (the
-        // 64x64 level: 768 tiles; at 32x32 / 16x16 - 384 / 192 tiles on 256 CUs - "apply, then the v2 / v3 kernels" measured 12-15 % faster)
-        {
-            const long long tiles = (p.M / 192) * (p.N / 320), cus = v3d_num_cus();
-            if (tiles >= cus / 2 && tiles * 10 < ((tiles + cus - 1) / cus) * cus * 9) return 0;      // (small launches: nothing to lose)
-        }
         if (p.gn_in && p.gn_in_rps != (long long)p.T * p.S) return 0;      // the 3-D GroupNorm: one row per sample
         if (p.gn_stats && (p.gn_rps != (long long)p.T * p.S || p.gn_nslots < (p.T / 6) * (p.S / 32) * 2)) return 0;
         return 4;

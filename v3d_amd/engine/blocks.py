@@ -115,7 +115,14 @@ def convt3_gn(ops, x, norm, w, bias, g: "Geo", *, stats=None, **epi):
     n, S, T = g.n, g.S, g.T
     table = ops.groupnorm_table(x, None, ga, be, n, S, eps=eps, imgs_per_stat=T, stats=stats)
     N, K = w.shape[-2], x.shape[-1]
-    if _CONV_GN:
+    # Policy (the library answers whether it CAN, this is whether it PAYS): with 3 taps per chunk the temporal kernel has two steps of MFMA
+    # slots for its normalisation chain and 192 x 320 tiles only - measured (tools/conv_gn_bench.py, tools/op_times.py) it beats "apply, then
+    # the v3 / v2 / split-K kernels" only where those tiles fill the CUs: the 64x64 level (768 tiles, x1.08-1.15); 384 tiles at 32x32 x0.85,
+    # 192 at 16x16 x0.89, 48 at 8x8 x0.45.
+    tiles = (n * S // 192) * (N // 320) if N % 320 == 0 else 0
+    cus = getattr(ops, "cu_count", 256)
+    pays = getattr(ops, "always_fuse", False) or (tiles > 0 and tiles * 10 >= -(-tiles // cus) * cus * 9)
+    if _CONV_GN and pays:
         out = ops.empty((n * S, N), ops.act_dtype, x.device)
         call = GemmCall(A=x, W=w, out=out, M=n * S, N=N, K=K, bias=bias, mode=GEMM_CONVT3, T=T, S=S, tmin=0, tmax=T - 1,
                         gn_in=table, gn_in_rps=T * S, gn_in_silu=True, **epi)
