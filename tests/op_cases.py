@@ -8,6 +8,7 @@ fp32 elementwise ops: 1e-5.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -277,7 +278,7 @@ def case_attn_fp8(hip, emu, dev, *, n_img, S, heads, seed=0, what="attn"):
 
 
 def case_conv_gn(hip, emu, dev, *, N, C1, C2=0, conv=None, convt=None, add=False, res=0, coef=False, gn_out=False, silu=True, seed=0,
-                 expect_fused=True, mean=0.5):
+                 expect_fused=True, mean=0.5, expect_streamk=None):
     """GroupNorm (+SiLU) in the operand path of the convolution (GemmCall.gn_in / A2): the LDS-haloed kernels normalise the raw input
     tile on its way into LDS.  Reference = the emulation (normalise -> round to bf16 -> convolution); the statistics table comes from the
     product's own stats / finalize kernels.  conv = (n_img, H, W) 3x3 stride 1; convt = (B, T, S) the (3,1,1) conv with the 3-D norm."""
@@ -322,7 +323,10 @@ def case_conv_gn(hip, emu, dev, *, N, C1, C2=0, conv=None, convt=None, add=False
     assert fused == expect_fused, f"gemm_gn_in_supported = {fused}, the case expects {expect_fused}"
     if not fused:
         return 0.0, 1.0
+    sk0 = _sk_counter(hip, "v3d_debug_sk_launches")
     hip.gemm(call)
+    if expect_streamk is not None and os.environ.get("V3D_STREAMK", "1") != "0":
+        assert (_sk_counter(hip, "v3d_debug_sk_launches") > sk0) == expect_streamk, "stream-K plan: the launch did not take the expected path"
     emu.gemm(GemmCall(out=o_e, **base, **skw_e))
     o_2 = torch.zeros_like(o_h)
     if gn_out:
@@ -336,7 +340,22 @@ def case_conv_gn(hip, emu, dev, *, N, C1, C2=0, conv=None, convt=None, add=False
     else:
         hip.gemm(GemmCall(out=o_2, **base))
     assert torch.equal(o_2, o_h), "two identical launches of the haloed kernel differ"
+    _assert_no_sk_timeouts(hip)
     return compare(o_h, o_e)
+
+
+def _sk_counter(hip, name):
+    import ctypes
+    fn = getattr(hip.lib, name)
+    fn.restype = ctypes.c_longlong
+    fn.argtypes = []
+    return int(fn())
+
+
+def _assert_no_sk_timeouts(hip):
+    """stream-K tail of the persistent kernels: an owner piece that gave up waiting for a donor's partial (bounded spin) would still return -
+    with a wrong tile.  The library counts those; the count must stay 0."""
+    assert _sk_counter(hip, "v3d_debug_sk_timeouts") == 0, "a stream-K hand-off timed out"
 
 
 def case_convt3_split_halo(hip, emu, dev, *, B, T, S, N, K, first=False, last=False, seed=0):
@@ -476,6 +495,8 @@ def all_cases(full: bool = True):
         ("conv_gn_64_concat_res", case_conv_gn, dict(N=320, C1=64, C2=32, conv=(3, 64, 64), res=1, seed=2), TOL_BF16),
         ("conv_gn_32_n640", case_conv_gn, dict(N=640, C1=96, conv=(6, 32, 32), add=True, gn_out=True, seed=3), TOL_BF16),
         ("conv_gn_16_n1280", case_conv_gn, dict(N=1280, C1=64, C2=64, conv=(12, 16, 16), res=1, gn_out=True, seed=4), TOL_BF16),
+        # 48 tiles of 40 chunks on 256 CUs: stream-K tail with five or six blocks per tile (one owner piece + several donors, added in block order)
+        ("conv_gn_16_streamk_many_donors", case_conv_gn, dict(N=320, C1=1280, conv=(36, 16, 16), res=1, gn_out=True, seed=10, expect_streamk=True), TOL_BF16),
         ("conv_gn_64_offcentre", case_conv_gn, dict(N=320, C1=64, conv=(3, 64, 64), mean=30.0, seed=5), TOL_BF16),
         ("conv_gn_nosilu", case_conv_gn, dict(N=320, C1=32, conv=(3, 32, 32), silu=False, seed=6), TOL_BF16),
         ("conv_gn_unsupported_8x8", case_conv_gn, dict(N=1280, C1=64, conv=(36, 8, 8), expect_fused=False), TOL_BF16),
@@ -533,12 +554,12 @@ def all_cases(full: bool = True):
             ("gemm_V3D_qk_L2", case_gemm, dict(M=36 * 256, N=2560, K=1280, bias=False), TOL_BF16),
             ("gemm_V3D_emb_M36", case_gemm, dict(M=36, N=1280, K=1280, out_fp32=True), TOL_BF16),
             ("conv3x3_V3D_L0", case_gemm, dict(M=0, N=320, K=320, mode=C3, conv=(4, 64, 64, 1, 1), add=True), TOL_BF16),
-            ("conv_gn_V3D_L0_in", case_conv_gn, dict(N=320, C1=320, conv=(36, 64, 64), add=True, gn_out=True, seed=21), TOL_BF16),
+            ("conv_gn_V3D_L0_in", case_conv_gn, dict(N=320, C1=320, conv=(36, 64, 64), add=True, gn_out=True, seed=21, expect_streamk=False), TOL_BF16),
             ("conv_gn_V3D_L0_concat960", case_conv_gn, dict(N=320, C1=640, C2=320, conv=(6, 64, 64), add=True, gn_out=True, seed=22), TOL_BF16),
-            ("conv_gn_V3D_L1_out", case_conv_gn, dict(N=640, C1=640, conv=(36, 32, 32), res=1, gn_out=True, seed=23), TOL_BF16),
+            ("conv_gn_V3D_L1_out", case_conv_gn, dict(N=640, C1=640, conv=(36, 32, 32), res=1, gn_out=True, seed=23, expect_streamk=True), TOL_BF16),
             ("conv_gn_V3D_L2_concat2560", case_conv_gn, dict(N=1280, C1=1280, C2=1280, conv=(36, 16, 16), add=True, gn_out=True, seed=24), TOL_BF16),
             ("convt_gn_V3D_L0", case_conv_gn, dict(N=320, C1=320, convt=(2, 18, 4096), res=1, coef=True, seed=25), TOL_BF16),
-            ("convt_gn_V3D_L1", case_conv_gn, dict(N=640, C1=640, convt=(2, 18, 1024), add=True, gn_out=True, seed=26), TOL_BF16),
+            ("convt_gn_V3D_L1", case_conv_gn, dict(N=640, C1=640, convt=(2, 18, 1024), add=True, gn_out=True, seed=26, expect_streamk=True), TOL_BF16),
             ("conv3x3_V3D_L3_2560", case_gemm, dict(M=0, N=1280, K=2560, mode=C3, conv=(36, 8, 8, 1, 1), res=1), TOL_BF16),
             ("conv3x3_V3D_down", case_gemm, dict(M=0, N=320, K=320, mode=C3, conv=(4, 64, 64, 2, 1)), TOL_BF16),
             ("conv3x3_V3D_up", case_gemm, dict(M=0, N=640, K=640, mode=C3, conv=(4, 32, 32, 1, 2)), TOL_BF16),

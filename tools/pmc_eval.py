@@ -49,6 +49,13 @@ def _rec_lnff(xx, eps, w1p, b1, w2p, b2, out, **kw):       # v3d_ln_ff_fused: th
 
 
 _ops.gemm, _ops.ff_fused, _ops.ln_ff_fused = _rec_gemm, _rec_ff, _rec_lnff
+# window marker (tools/pmc_traffic.py counts only dispatches behind the first copy2d): everything above - model build, packing, input
+# synthesis, one warm-up evaluation that triggers the lazy packing - is setup
+denoiser(wrapped, x, sig, cond, **extra)
+_calls.clear()
+torch.cuda.synchronize()
+_mk = torch.zeros(16, 64, device=dev).bfloat16()
+_ops.copy2d_bf16(_mk, torch.empty_like(_mk))
 for _ in range(N_EVAL):
     denoiser(wrapped, x, sig, cond, **extra)
 torch.cuda.synchronize()

@@ -33,7 +33,7 @@ def main():
     calls = json.load(open(sys.argv[3]))["calls"]
     ff = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
     fw = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
-    is_main = lambda n: ("gemm_kernel_v" in n) or ("ff_fused_kernel" in n)
+    is_main = lambda n: ("gemm_kernel_v" in n) or ("ff_fused_kernel" in n) or ("conv_halo_kernel" in n)
     fg = [d for d in fetch if is_main(d[1])]
     wg = [d for d in write if is_main(d[1])]
     print(f"{len(calls)} recorded calls, {len(fg)} / {len(wg)} GEMM-family dispatches in the FETCH / WRITE passes")

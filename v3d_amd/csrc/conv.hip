@@ -121,8 +121,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     constexpr int WSTAGE = BN * ROWB;                     // 20 KiB of weights per (chunk, tap) step
     constexpr int EPI_REGION = 16 * (NF * 32 + 16);
     constexpr int RING_OFF = 0, HALO_OFF = NS * WSTAGE, ZERO_OFF = HALO_OFF + NBUF * HBYTES, TAB_OFF = ZERO_OFF + 1024,
-                  EPI_OFF = TAB_OFF + NW * 512 * G::NTAB;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_OFF + NW * EPI_REGION];   // the ONLY __shared__ object
+                  EPI_OFF = TAB_OFF + NW * 512 * G::NTAB, SK_OFF = EPI_OFF + NW * EPI_REGION;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[SK_OFF + SK_TAB_BYTES];        // the ONLY __shared__ object
     static_assert(sizeof(lds) <= 160 * 1024, "LDS budget");
 
     const int tid = threadIdx.x;
@@ -132,16 +132,23 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     const int wm = wave >> 2, wn = wave & 3;             // waves 2 (M) x 4 (N): wave tile 96 x 80
     unsigned char* estage = lds + EPI_OFF + wave * EPI_REGION;
 
+    // work list of the block: whole tiles, then (with a stream-K plan, gemm_common.h sk_*) a donor piece and / or an owner piece of the last
+    // round's tiles, cut at 32-channel chunks.  The three cursors below (weights, halo, consumer) walk the same (item, chunk) sequence.
+    const int nchunks = (int)(p.K / 32);
     const int Gd = gridDim.x;
-    const int my_tiles = (ntiles - (int)blockIdx.x + Gd - 1) / Gd;
-    auto tile_origin = [&](int it, int& tm, long long& n0) __attribute__((always_inline)) {
-        const int id = xcd_remap((int)blockIdx.x + it * Gd, ntiles);
+    const int* sktab = reinterpret_cast<const int*>(lds + SK_OFF);
+    if (tid == 0) sk_build_table(p, (int)blockIdx.x, Gd, ntiles, nchunks, reinterpret_cast<int*>(lds + SK_OFF));
+    __syncthreads();
+    const int my_items = __builtin_amdgcn_readfirstlane(sktab[0]);
+    const int my_donor = __builtin_amdgcn_readfirstlane(sktab[1]);      // 1: item 0 is a donor piece
+    auto item_at = [&](int i) __attribute__((always_inline)) -> SkItem { return sk_item(p, (int)blockIdx.x, Gd, i, my_items, my_donor, nchunks, sktab); };
+    auto tile_origin = [&](int raw, int& tm, long long& n0) __attribute__((always_inline)) {
+        const int id = xcd_remap(raw, ntiles);
         int tn;
         tile_coords(p, id, tm, tn);
         n0 = (long long)tn * BN;
     };
     // first source pixel row of tile row-block tm (3x3: flat pixel order; temporal: (sample, frame block, position block))
-    const int nchunks = (int)(p.K / 32);
     const int k1chunks = (int)(p.K1 / 32);
     const int H = p.Hout;
     const int sblocks = HM == HM_TEMP ? (int)(p.S / 32) : 1;      // temporal: position blocks per frame
@@ -152,15 +159,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     const int prow = lane >> 2;
     const unsigned kchunk_w = (unsigned)(((lane & 3) ^ wswz(prow)) * 16);
     const unsigned voffW = (unsigned)(prow * (int)p.ldw * 2) + kchunk_w;     // per-lane part of a weight piece's source offset (row inside the piece, k-chunk)
-    int w_it = 0, w_c = 0;                                // weight cursor: tile, chunk (its tap is static in the unrolled step bodies)
+    int w_it = 0, w_c = 0, w_c1 = nchunks;                // weight cursor: item, chunk, end chunk of the item (its tap is static in the unrolled step bodies)
     int w_n0 = 0;                                         // first output channel of the cursor's tile
     const unsigned tap_bytes = (unsigned)(p.N * p.ldw * 2);
     const int row16_bytes = (int)(16 * p.ldw * 2);
     auto set_wtile = [&](int it) __attribute__((always_inline)) {
         int tm;
         long long n0 = 0;
-        if (it < my_tiles) tile_origin(it, tm, n0);      // (past the last tile: harmless re-reads of tile column 0 keep the DMA count constant)
+        const SkItem q = item_at(it);
+        if (q.tile >= 0) tile_origin(q.tile, tm, n0);    // (past the last item: harmless re-reads of tile column 0 keep the DMA count constant)
         w_n0 = (int)n0;
+        w_c = q.u0;
+        w_c1 = q.u1;
     };
     auto issue_w = [&](int stage, int ltap) __attribute__((always_inline)) {
         if (CABL(4)) return;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     const bufrsrc_t rsA1 = make_rsrc(p.A, p.a_bytes);
     const bufrsrc_t rsA2 = make_rsrc(p.A2 ? p.A2 : p.A, p.A2 ? p.a2_bytes : p.a_bytes);
     const bufrsrc_t rsT = make_rsrc(p.gn_in ? (const void*)p.gn_in : (const void*)p.A, p.gn_in ? p.gn_in_bytes : 0u);
-    int h_it = 0, h_c = 0, h_buf = 0;                    // halo cursor: tile, chunk, LDS image it writes
+    int h_it = 0, h_c = 0, h_c1 = 0, h_buf = 0;          // halo cursor: item, chunk, end chunk of the item, LDS image it writes
     // per-tile state of the cursor, all wave-uniform (the per-lane source rows are recomputed where they are used: a dozen VALU per piece and
     // chunk against registers held through every step)
     struct HTile {
@@ -198,8 +208,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     auto set_htile = [&](int it) __attribute__((always_inline)) {
         int tm = 0;
         long long n0;
-        ht.live = it < my_tiles;
-        if (ht.live) tile_origin(it, tm, n0);
+        const SkItem q = item_at(it);
+        ht.live = q.tile >= 0;
+        if (ht.live) tile_origin(q.tile, tm, n0);
+        h_c = q.u0;
+        h_c1 = q.u1;
         const long long rps = p.gn_in_rps > 0 ? p.gn_in_rps : 1;
         if (HM == HM_CONV) {
             const int fr0 = tm * (BM / W_);                                    // first flat image row of the tile
@@ -218,8 +231,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         }
     };
     // source pixel row of this lane's halo pixel of piece i in tile t (kInvalid: padding / outside the tensor); second = it belongs to statB
-    auto halo_row = [&](const HTile& t, int i, bool& second) __attribute__((always_inline)) -> unsigned {
-        const int hp = (wave + NW * i) * 16 + (lane >> 2);
+    // (ln = an OPAQUE copy of the lane id, made where the rows are needed: as loop invariants the pieces' (line, x) pairs were hoisted in front of
+    // the main loop, a dozen registers held through every step - or, once the loop was a register short, re-read from scratch inside it)
+    auto halo_row = [&](const HTile& t, int i, bool& second, int ln) __attribute__((always_inline)) -> unsigned {
+        const int hp = (wave + NW * i) * 16 + (ln >> 2);
         second = false;
         if (HM == HM_CONV) {
             const int line = hp / LINE, x = hp - line * LINE - 1;
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     };
     auto issue_halo = [&]() __attribute__((always_inline)) {
         if (CABL(8192)) return;
-        if (h_c == 0) set_htile(h_it);
+        if (h_c == h_c1) set_htile(h_it);                 // (cursor at the end of its item - or at the very start: 0 == 0 - : enter item h_it)
         const bool second = h_c >= k1chunks;
         const int cc = second ? h_c - k1chunks : h_c;
         const unsigned ld2 = (unsigned)((second ? p.lda2 : p.lda) * 2);
@@ -250,8 +265,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             // (scale, shift) of this chunk's 32 channels for the (at most two) statistics groups of the halo: 2 x 256 B
             const unsigned st = lane < 16 ? ht.statA : ht.statB;
             const unsigned vo = (unsigned)(((long long)st * p.K + (long long)h_c * 32) * 8) + (unsigned)(lane & 15) * 16u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (__attribute__((address_space(3))) void*)(lds + TAB_OFF + (wave * G::NTAB + h_tab) * 512), 16, (int)(h_it < my_tiles ? vo : kInvalid), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (__attribute__((address_space(3))) void*)(lds + TAB_OFF + (wave * G::NTAB + h_tab) * 512), 16, (int)(ht.live ? vo : kInvalid), 0, 0, 0);
         }
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         latch_base = (unsigned)(HALO_OFF + h_buf * HBYTES);
         xt = ht;                                          // (the chain of this image starts after the issue: xf_begin picks these up)
         x_tab = h_tab;
@@ -259,15 +276,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
 #pragma unroll
         for (int i = 0; i < HPW; ++i) {
             bool second_stat;
-            const unsigned row = halo_row(ht, i, second_stat);
+            const unsigned row = halo_row(ht, i, second_stat, ln);
             const unsigned vo = row == kInvalid ? kInvalid : row * ld2 + (unsigned)hchunkpos * 16u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rsA2 : rsA1, (__attribute__((address_space(3))) void*)(lds + HALO_OFF + h_buf * HBYTES + (wave + NW * i) * 1024), 16,
                                                      (int)vo, cc * 64, 0, 0);
         }
-        if (++h_c == nchunks) {
-            h_c = 0;
-            ++h_it;
-        }
+        if (++h_c == h_c1) ++h_it;
         h_buf = h_buf + 1 == NBUF ? 0 : h_buf + 1;
     };
     // ---------------------------------------------------------------- the in-place normalisation of the image the loader filled last
@@ -339,10 +353,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             xf_base = latch_base;
             ct = xt;
             c_tab = x_tab;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
 #pragma unroll
             for (int v = 0; v < HPW; ++v) {
                 bool second;
-                const unsigned row = halo_row(ct, v, second);
+                const unsigned row = halo_row(ct, v, second, ln);
                 ctab[v] = (row == kInvalid ? (unsigned)ZERO_OFF : (unsigned)(TAB_OFF + (wave * G::NTAB + c_tab) * 512) + (second ? 256u : 0u)) + (unsigned)hchunkpos * 64u;
             }
             xs.raw = xf_read_vec(0);
@@ -406,10 +422,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     __builtin_amdgcn_sched_barrier(0);
 
     int rd = 0;                                           // ring slot of the current step
-    for (int it = 0; it < my_tiles; ++it) {
+    // one item: its chunks, then its retirement.  DONOR = the item is the block's donor piece (a compile-time copy of the loop, see sk_item)
+    auto run_item = [&](int it, auto donor_) __attribute__((always_inline)) {
+        constexpr bool DONOR = decltype(donor_)::value;
         int tm;
         long long e_n0;
-        tile_origin(it, tm, e_n0);
+        const SkItem item = item_at(it);
+        tile_origin(item.tile, tm, e_n0);
         if (HM == HM_CONV) {
             vmask = 0;
 #pragma unroll
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             }
             vmask = (unsigned)__builtin_amdgcn_readfirstlane((int)vmask);
         }
-        for (int c = 0; c < nchunks; ++c) {
+        for (int c = item.u0; c < item.u1; ++c) {
             static_for<0, NT>([&](auto tap_) {
                 constexpr int tap = decltype(tap_)::value;
                 constexpr int dy = HM == HM_CONV ? tap / 3 : tap, dx = HM == HM_CONV ? tap % 3 : 0;
@@ -449,10 +468,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 if constexpr (tap == G::XF0 % NT) xf_begin();     // (ahead of this step's issue: with NT <= XF0 the chain belongs to the PREVIOUS issue)
                 if constexpr (tap == 0) issue_halo();
                 if constexpr (ltap == 0) {                            // the weight cursor enters the next chunk
-                    if (++w_c == nchunks) {
-                        w_c = 0;
-                        set_wtile(++w_it);
-                    }
+                    if (++w_c == w_c1) set_wtile(++w_it);
                 }
                 issue_w(rd == 0 ? NS - 1 : rd - 1, ltap);
                 rd = (rd + 1 == NS) ? 0 : rd + 1;
@@ -496,8 +512,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 for (int dx = 0; dx < NDX; ++dx) faddr[dx] += d;
             }
         }
-        // ---------------- tile finished for this group: retire it (v3 epilogue: 16-row chunks through the wave's staging region)
-        if (CABL(1)) {
+        // ---------------- item finished for this group.  Donor piece: park the accumulators for the tile's owner.  Owner piece: add the donors'.
+        // Then (whole tile / owner) retire it (v3 epilogue: 16-row chunks through the wave's staging region)
+        if constexpr (DONOR) {
+            sk_publish<MF, NF>(p, acc, (int)blockIdx.x, wave, lane);
+        } else if (CABL(1)) {
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < MF; ++i)
@@ -542,13 +561,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             // were hoisted in front of the main loop, spilled there, and re-read from scratch ~20 times per fragment)
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
+            const SkItem done = item_at(it);          // (re-read: role / donors are not carried through the chunk loop)
+            if (done.role == 2) sk_gather<MF, NF>(p, acc, done.d0, done.d1, wave, lane_e, Gd);
             e4_retire_tile<MF, NF, GN>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    };
+    if (my_donor) run_item(0, std::true_type{});
+    for (int it = my_donor; it < my_items; ++it) run_item(it, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -593,7 +616,8 @@ static int conv_halo_launch_t(const V3dGemmParams& p0, hipStream_t st) {
     p.mt = (int)(p.M / 192);
     p.nt = (int)(p.N / 320);
     const int ntiles = p.mt * p.nt;
-    const int grid = ntiles < v3d_num_cus() ? ntiles : v3d_num_cus();
+    // (stream-K tail: the last round's tiles are cut at 32-channel chunks and shared out over all CUs; at least 4 chunks per piece)
+    const int grid = v3d_sk_plan(p, ntiles, (int)(p.K / 32), 4, (size_t)192 * 320 * 4, (void*)st);
     const bool xf = p.gn_in != nullptr, gn = p.gn_stats != nullptr;
     if (xf && gn) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
     else if (xf) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, false>), dim3(grid), dim3(512), 0, st, p, ntiles);

@@ -19,6 +19,7 @@
 
 #include <map>
 #include <mutex>
+#include <vector>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -903,6 +904,71 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
 // tests only (not part of the ABI header)
 extern "C" long long v3d_debug_gn_epilogue_launches(void) { return g_gn_epilogue_launches; }
 
+// ---- stream-K plan (device side: gemm_common.h sk_*) ---------------------------------------------------------------------------------------
+namespace {
+struct SkWorkspace {
+    hipStream_t st;
+    float* ws;
+    unsigned* flags;
+    size_t slot_bytes;
+    int G;
+};
+std::vector<SkWorkspace> g_sk;       // (one per stream that ever planned a stream-K launch; never freed: captured graphs point into them)
+std::mutex g_sk_mu;
+long long g_sk_launches = 0;
+}  // namespace
+
+int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, size_t slot_bytes, void* stream) {
+    p.sk_tail = p.sk_full = 0;
+    p.sk_units = units;
+    p.sk_ws = nullptr;
+    p.sk_flags = nullptr;
+    const int G = v3d_num_cus();
+    const int classic = ntiles < G ? ntiles : G;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V3D_STREAMK"); on = e ? atoi(e) : 1; }          // A/B knob: 0 = classic tile assignment everywhere
+    const int full = ntiles / G, R = ntiles % G;
+    // worth it when the partial round leaves >= 1/8 of the chip idle and every block still gets a piece of >= min_units granules
+    if (!on || R == 0 || (G - R) * 8 < G || (long long)R * units / G < min_units) return classic;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    const SkWorkspace* w = nullptr;
+    for (const SkWorkspace& c : g_sk)
+        if (c.st == st && c.slot_bytes >= slot_bytes && c.G == G) w = &c;
+    if (!w) {
+        // one workspace per stream (launches on one stream run back to back; two streams must not share slots); never allocated inside a capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return classic; }
+        SkWorkspace n = {st, nullptr, nullptr, slot_bytes, G};
+        if (hipMalloc(reinterpret_cast<void**>(&n.ws), (size_t)G * slot_bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&n.flags), ((size_t)G * 8 + 16) * 4) != hipSuccess ||
+            hipMemset(n.flags, 0, ((size_t)G * 8 + 16) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return classic;
+        }
+        g_sk.push_back(n);
+        w = &g_sk.back();
+    }
+    p.sk_tail = R;
+    p.sk_full = full;
+    p.sk_ws = w->ws;
+    p.sk_flags = w->flags;
+    ++g_sk_launches;
+    return G;
+}
+
+// tests only: launches planned with a stream-K tail; hand-offs that gave up waiting (must stay 0)
+extern "C" long long v3d_debug_sk_launches(void) { return g_sk_launches; }
+extern "C" long long v3d_debug_sk_timeouts(void) {
+    long long t = 0;
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    for (const SkWorkspace& c : g_sk) {
+        unsigned v = 0;
+        if (hipMemcpy(&v, c.flags + (size_t)c.G * 8, 4, hipMemcpyDeviceToHost) == hipSuccess) t += v;
+    }
+    return t;
+}
+
 // experiments only (not part of the ABI header): copy the v3 slot timeline out
 extern "C" int v3d_debug_v3_timeline(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_v3_dbg), sizeof(g_v3_dbg)) == hipSuccess ? 0 : -1;
@@ -960,6 +1026,7 @@ int fill_params(const v3d_gemm_args* a, GP& p, int* halo) {
     p.split_n = 1;
     p.ws = nullptr;
     p.ablate = 0;
+    p.sk_tail = p.sk_full = p.sk_units = 0; p.sk_ws = nullptr; p.sk_flags = nullptr;
 #ifdef V3D_EXPERIMENTS
     { static int ab = -1; if (ab < 0) { const char* e = getenv("V3D_GEMM_ABLATE"); ab = e ? atoi(e) : 0; } p.ablate = ab; }
 #endif

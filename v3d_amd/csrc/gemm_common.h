@@ -54,11 +54,20 @@ struct V3dGemmParams {
     long long gn_in_rps;
     int gn_in_silu;
     unsigned gn_in_bytes;   // size of the table (buffer descriptor)
+    // stream-K tail of the persistent kernels (sk_* helpers below): 0 = classic (tiles b, b + G, ... per block)
+    int sk_tail;         // tiles of the last, partial round, shared out over ALL blocks in units of sk_units-th of a tile
+    int sk_full;         // full rounds in front of it (tiles b + i * G, i < sk_full)
+    int sk_units;        // split granules per tile (conv.hip: 32-channel chunks; gemm.hip v3: 32-k steps)
+    float* sk_ws;        // partial accumulators: one slot per block [G][8 waves][MF * NF][64 lanes] f32x4
+    unsigned* sk_flags;  // [G][8]: 1 = wave w of block g has published its partial (reset to 0 by the consumer)
 };
 
 // conv.hip: the LDS-haloed kernels (GroupNorm + SiLU in the operand path)
 int v3d_conv_halo_variant(const V3dGemmParams& p, int mode);          // 0 = not one of their shapes
 int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream);
+// gemm.hip: stream-K plan of a persistent launch (fills p.sk_*, returns the grid): ntiles tiles of `units` split granules on the device's CUs;
+// slot_bytes = one block's accumulators in fp32.  Leaves the classic assignment (sk_tail = 0) when the tail round is full enough or too thin.
+int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, size_t slot_bytes, void* stream);
 
 namespace {
 
@@ -716,6 +725,146 @@ __device__ __forceinline__ void e4_retire_tile(const GP& p, f32x4 (&acc)[MF][NF]
     GnAcc<GN ? NF : 1> gn;
     if constexpr (GN) gn_zero(gn);
     e4_retire<0, MF, NF, GN>(p, acc, nw0, lane, stage, cur, t, gn, rowfn, flushfn);
+}
+
+// ---- stream-K tail ------------------------------------------------------------------------------------------------------------------------
+// A persistent launch of `ntiles` tiles on G blocks (one per CU) leaves CUs idle in its last round unless ntiles % G == 0: the 32 x 32 level
+// of the U-Net runs 384 tiles (1.5 rounds: half the chip idles through the second), the 16 x 16 level 192 (a quarter idles throughout).  With a
+// plan (v3d_sk_plan) the R = ntiles % G tiles of that last round are cut along K into R * U granules (U per tile) and block b takes the
+// granules [b R U / G, (b + 1) R U / G): at most two pieces of two neighbouring tiles.  A piece that starts inside a tile is a DONOR piece:
+// the block runs it FIRST, parks its fp32 accumulators in its workspace slot (16-byte write-through stores, MI355X_MICROARCH.md "publish-large")
+// and raises one flag per wave.  A piece that starts a tile is the OWNER piece: the block runs it LAST, then adds the donors' partials in
+// block order (a fixed order: the result does not depend on timing) and runs the normal epilogue.  Donors never wait, owners wait only for
+// donors, every block is resident (G <= CUs, one block per CU): no cycle.  Hand-off per wave, not per block (wave w of the owner consumes what
+// wave w of the donor stored - same lanes, same registers), so the two wave groups of a block keep their half-step offset through it.
+struct SkItem {
+    int tile;      // raw tile id (before xcd_remap); < 0: past the block's work (loaders keep their DMA counts with harmless re-reads)
+    int u0, u1;    // granules [u0, u1) of the tile
+    int role;      // 0 whole tile, 1 donor piece, 2 owner piece
+    int d0, d1;    // owner: blocks d0 .. d1 hold the rest of the tile
+};
+// Order of a block's items: its donor piece FIRST (published long before the owner - which runs that tile's head as ITS last item - asks for
+// it), then its whole tiles, then its owner piece.  (The donor piece also gets its own copy of the main loop in the kernels: one loop with
+// all three ways of retiring an item - park / epilogue / gather + epilogue - pushed accumulators into scratch inside the loop.)
+// The work list is computed once, by one thread, into a 96-byte LDS table (the divisions cost ~300 instructions and a dozen registers);
+// U = granules per tile as the KERNEL counts them (the host planned with the same number).
+// tab[0] = items of the block, tab[1] = 1 if item 0 is a donor piece, tab[4 + 8 k ..] = its k-th piece of the last round (k < 2).
+constexpr int SK_TAB_BYTES = 96;
+__device__ __forceinline__ void sk_build_table(const GP& p, int b, int G, int ntiles, int U, int* tab) {
+    tab[1] = 0;
+    if (p.sk_tail == 0) {
+        tab[0] = (ntiles - b + G - 1) / G;
+        return;
+    }
+    const long long RU = (long long)p.sk_tail * U;
+    const long long lo = b * RU / G, hi = (b + 1) * RU / G;
+    int n = 0;
+    for (long long a = lo; a < hi; ++n) {
+        const long long jt = a / U, t0 = jt * U, t1 = t0 + U;
+        const long long e = hi < t1 ? hi : t1;
+        int* q = tab + 4 + 8 * n;
+        q[0] = p.sk_full * G + (int)jt;          // raw tile id
+        q[1] = (int)(a - t0);                    // granules [u0, u1)
+        q[2] = (int)(e - t0);
+        q[3] = a > t0 ? 1 : (e < t1 ? 2 : 0);    // donor piece / owner piece / whole tile
+        q[4] = b + 1;                            // owner: blocks d0 .. d1 hold the rest of the tile (d1 = last block whose range starts inside it)
+        q[5] = (int)((t1 * G + RU - 1) / RU) - 1;
+        if (n == 0 && q[3] == 1) tab[1] = 1;
+        a = e;
+    }
+    tab[0] = p.sk_full + n;
+}
+__device__ __forceinline__ SkItem sk_item(const GP& p, int b, int G, int i, int nitems, int ndonor, int U, const int* tab) {
+    SkItem it;
+    it.u0 = 0; it.u1 = U; it.role = 0; it.d0 = it.d1 = 0;
+    it.tile = i < nitems ? b + (i - ndonor) * G : -1;
+    if (p.sk_tail != 0 && i < nitems && (i < ndonor || i >= ndonor + p.sk_full)) {
+        const int* q = tab + 4 + 8 * (i < ndonor ? 0 : ndonor);
+        it.tile = __builtin_amdgcn_readfirstlane(q[0]);
+        it.u0 = __builtin_amdgcn_readfirstlane(q[1]);
+        it.u1 = __builtin_amdgcn_readfirstlane(q[2]);
+        it.role = __builtin_amdgcn_readfirstlane(q[3]);
+        it.d0 = __builtin_amdgcn_readfirstlane(q[4]);
+        it.d1 = __builtin_amdgcn_readfirstlane(q[5]);
+    }
+    return it;
+}
+// donor: park the wave's accumulators (slot = the block), publish.  Every VMEM op of the wave has drained before the flag leaves (the LDS-DMA
+// prefetches in flight included: a bubble of one memory round trip, once per launch and block).
+template <int MF, int NF>
+__device__ __forceinline__ void sk_publish(const GP& p, const f32x4 (&acc)[MF][NF], int blk, int wave, int lane) {
+    // (opaque lane id: as loop invariants the 30 store addresses were hoisted in front of the main loop and spilled there)
+    asm volatile("" : "+v"(lane));
+    const float* base = p.sk_ws + ((size_t)blk * 8 + wave) * (MF * NF) * 256;            // wave-uniform: SGPR pair
+    unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int k = i * NF + j;
+            if (k % 4 == 0 && k > 0) voff += 4096u;
+            // (s_nop 1: a VALU write to the data registers of a 16-byte store needs two wait states behind it; the compiler inserts them for its
+            // own stores, not behind inline asm - its next instruction re-used the first data register for the next offset and the lanes the
+            // memory pipeline reads last, 12..15 of every 16, stored that instead)
+            switch (k % 4) {       // (immediate offsets reach 4095 bytes: four 1-KiB fragments per base step)
+                case 0: asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(acc[i][j]), "s"(base) : "memory"); break;
+                case 1: asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(acc[i][j]), "s"(base) : "memory"); break;
+                case 2: asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(acc[i][j]), "s"(base) : "memory"); break;
+                default: asm volatile("global_store_dwordx4 %0, %1, %2 offset:3072 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(acc[i][j]), "s"(base) : "memory"); break;
+            }
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(p.sk_flags + blk * 8 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// owner: acc += the partials of blocks d0 .. d1, in that order.  Bounded spin (a donor that never shows up would otherwise hang the device).
+template <int MF, int NF>
+__device__ __forceinline__ void sk_gather(const GP& p, f32x4 (&acc)[MF][NF], int d0, int d1, int wave, int lane, int G) {
+    asm volatile("" : "+v"(lane));
+    for (int d = d0; d <= d1; ++d) {
+        unsigned* flag = p.sk_flags + d * 8 + wave;
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 21); ++spin) {
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok) {
+            if (lane == 0) atomicAdd(p.sk_flags + G * 8, 1u);      // (word behind the flags: hand-offs that gave up - never expected, tests read it)
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float* base = p.sk_ws + ((size_t)d * 8 + wave) * (MF * NF) * 256;          // wave-uniform: SGPR pair
+        // two fragment rows (2 NF vectors) per round trip.  The loads are inline asm: a destination register holds nothing until the wait
+        // below, and nothing may touch it before - so every destination is an operand of the wait statement itself (a copy or a spill the
+        // register allocator placed between a load and a later, anonymous wait would move the register's OLD content: seen as launch-to-
+        // launch differences in the first version, which kept a second row in flight across the adds).
+        static_assert(MF % 2 == 0, "rows are gathered in pairs");
+        auto load = [&](f32x4& dst, int k) __attribute__((always_inline)) {
+            const unsigned voff = (unsigned)lane * 16u + (unsigned)(k / 4) * 4096u;
+            switch (k % 4) {
+                case 0: asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(dst) : "v"(voff), "s"(base) : "memory"); break;
+                case 1: asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 sc0 sc1" : "=v"(dst) : "v"(voff), "s"(base) : "memory"); break;
+                case 2: asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 sc0 sc1" : "=v"(dst) : "v"(voff), "s"(base) : "memory"); break;
+                default: asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 sc0 sc1" : "=v"(dst) : "v"(voff), "s"(base) : "memory"); break;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < MF; i += 2) {
+            f32x4 r[2 * NF];
+#pragma unroll
+            for (int j = 0; j < 2 * NF; ++j) load(r[j], i * NF + j);
+            if constexpr (NF == 5)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9])::"memory");
+            else if constexpr (NF == 4)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+            else
+                static_assert(NF == 4 || NF == 5, "wait statement for this fragment count");
+#pragma unroll
+            for (int j = 0; j < 2 * NF; ++j) acc[i + j / NF][j % NF] += r[j];
+        }
+        if (lane == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
 }
 
 // host: may a launch use the hand-managed epilogue? (wm x wn = wave tile)

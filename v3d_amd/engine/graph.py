@@ -71,7 +71,10 @@ class _Captured:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the stream the warm-up ran on: the library keeps its split-K / stream-K workspaces per stream and cannot allocate
+        # inside a capture - on a fresh stream those launches would fall back to their unsplit forms (other summation order: the replay
+        # would differ from eager in the last bits)
+        with torch.cuda.graph(self.graph, stream=side):
             self.out = fn(*self.static_args)
 
     def __call__(self, flat):
