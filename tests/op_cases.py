@@ -35,7 +35,7 @@ def compare(a: torch.Tensor, b: torch.Tensor):
 
 # ------------------------------------------------------------------------------------------------
 def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=True, add=False, res=0, coef=False,
-              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0, gn_rps=0):
+              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0, gn_rps=0, expect_streamk=None):
     """gn_rps > 0: the launch also gathers the GroupNorm partial sums of its output (GemmCall.gn_stats, 32 groups, gn_rps rows per statistics
     group); they are checked against sums over the rows the kernel itself stored (fp32 partials, one slot per writer: 2e-4 of the largest sum)
     and a second launch must reproduce output AND statistics bit for bit (no atomics anywhere)."""
@@ -99,8 +99,20 @@ def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=Tru
         assert err <= 2e-4, f"gn_stats epilogue: partial sums off by {err:.3e} of the largest sum"
         r_e, _ = compare(st_e.sum(dim=1), want)
         assert r_e <= 2e-2, f"emulated gn_stats far from the kernel's ({r_e:.3e})"
+        if expect_streamk is not None:
+            _assert_no_sk_timeouts(hip)
         return compare(out_h, out_e)
+    sk0 = _sk_counter(hip, "v3d_debug_sk_launches") if expect_streamk is not None else 0
     hip.gemm(GemmCall(out=out_h, **base))
+    if expect_streamk is not None:
+        # stream-K tail of the persistent v3 kernels (the last round's tiles shared out over all CUs): taken / not taken as the plan says,
+        # and a second launch reproduces the first bit for bit (partials are added in block order)
+        if os.environ.get("V3D_STREAMK", "1") != "0" and not os.environ.get("V3D_GEMM_IMPL"):
+            assert (_sk_counter(hip, "v3d_debug_sk_launches") > sk0) == expect_streamk, "stream-K plan: the launch did not take the expected path"
+        out_2 = torch.zeros_like(out_h)
+        hip.gemm(GemmCall(out=out_2, **base))
+        assert torch.equal(out_2, out_h), "two identical launches differ"
+        _assert_no_sk_timeouts(hip)
     emu.gemm(GemmCall(out=out_e, **base))
     return compare(out_h, out_e)
 
@@ -564,6 +576,11 @@ def all_cases(full: bool = True):
             ("conv3x3_V3D_down", case_gemm, dict(M=0, N=320, K=320, mode=C3, conv=(4, 64, 64, 2, 1)), TOL_BF16),
             ("conv3x3_V3D_up", case_gemm, dict(M=0, N=640, K=640, mode=C3, conv=(4, 32, 32, 1, 2)), TOL_BF16),
             ("conv3x3_V3D_out4", case_gemm, dict(M=0, N=4, K=320, mode=C3, conv=(4, 64, 64, 1, 1), out_fp32=True), TOL_BF16),
+            # partial last rounds of the persistent v3 kernels (192 / 384 tiles of 192 x 320 on 256 CUs).  Only the LDS-haloed convolution kernels
+            # carry a stream-K tail; in v3 the item cursor cost every launch more than the tails gained (NOTES.md 10.5) - these stay classic
+            ("lin_V3D_L2_ffout_partial_round", case_gemm, dict(M=9216, N=1280, K=5120, res=1, expect_streamk=False, seed=31), TOL_BF16),
+            ("lin_V3D_L1_ffout_partial_round", case_gemm, dict(M=36864, N=640, K=2560, res=2, expect_streamk=False, seed=32), TOL_BF16),
+            ("convt3_V3D_L2_partial_round", case_gemm, dict(M=0, N=1280, K=1280, mode=CT, convt=(2, 18, 256, 0, 0, 17), res=1, add=True, expect_streamk=False, seed=34), TOL_BF16),
             ("convt3_V3D_L1", case_gemm, dict(M=0, N=640, K=640, mode=CT, convt=(2, 18, 1024, 0, 0, 17), res=1, coef=True, add=True), TOL_BF16),
             ("gn2d_V3D_960_64x64", case_groupnorm, dict(n_img=4, S=4096, C1=640, C2=320), TOL_BF16),
             ("gn3d_V3D_L2", case_groupnorm, dict(n_img=36, S=256, C1=1280, imgs_per_stat=18), TOL_BF16),

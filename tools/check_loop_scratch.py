@@ -27,17 +27,32 @@ def main():
         if "v_mfma" not in body or (pats and not any(p in name for p in pats)):
             continue
         blocks = re.split(r"\n(\.LBB[0-9_]+:[^\n]*|; %bb\.[0-9]+:[^\n]*)", body)
-        per = collections.defaultdict(lambda: [0, 0])
+        # per innermost loop: MFMAs, scratch ops in HOT blocks (blocks every step runs: they hold MFMAs, the step barrier or LDS-DMA issues),
+        # scratch ops in the loop's other blocks (the loaders' item / tile / tap switches: run once per item, their compiler-made vmcnt(0)
+        # only makes the counted waits conservative)
+        per = collections.defaultdict(lambda: [0, 0, 0])
         for j in range(1, len(blocks), 2):
             m = re.search(r"in Loop: Header=(BB[0-9_]+) Depth=(\d+)", blocks[j])
             if m:
-                per[(m.group(1), int(m.group(2)))][0] += len(re.findall("v_mfma", blocks[j + 1]))
-                per[(m.group(1), int(m.group(2)))][1] += len(re.findall(r"scratch_(?:load|store)", blocks[j + 1]))
+                b = blocks[j + 1]
+                e = per[(m.group(1), int(m.group(2)))]
+                ns = len(re.findall(r"scratch_(?:load|store)", b))
+                e[0] += len(re.findall("v_mfma", b))
+                e[1 if re.search(r"v_mfma|s_barrier|buffer_load_dwordx4[^\n]*lds", b) else 2] += ns
+        # LDS-DMA issues wrapped in a readfirstlane "waterfall" loop INSIDE another loop: the compiler took a scalar operand of the DMA (the k
+        # offset) for lane-varying - e.g. because it came out of an integer division, which runs on the vector ALU.  (In a prologue: harmless.)
+        hdr = re.split(r"\n(\.LBB[0-9_]+:(?:[^\n]*\n\s*;[^\n]*)*)", body)
+        waterfalls = sum(1 for j in range(1, len(hdr), 2) if "Parent Loop" in hdr[j] and "Inner Loop Header" in hdr[j]
+                         and re.search(r"v_readfirstlane[^\n]*\n(?:[^\n]*\n){0,2}?[^\n]*v_cmp_eq[^\n]*\n[^\n]*s_and_saveexec[^\n]*\n(?:[^\n]*\n){0,2}?[^\n]*buffer_load_dwordx4[^\n]*lds[^\n]*\n[^\n]*s_xor_b64 exec",
+                                       hdr[j + 1][:800]))
         loops = {k: v for k, v in per.items() if v[0]}
         bad = {k: v for k, v in loops.items() if v[1]}
+        if waterfalls:
+            bad["waterfall"] = waterfalls
         total = len(re.findall(r"scratch_(?:load|store)", body))
         short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:70]
-        print(f"{'DIRTY' if bad else 'ok   '} {short:70s} mfma loops {len(loops)}  scratch ops in them {sum(v[1] for v in loops.values())}  (whole kernel {total})")
+        print(f"{'DIRTY' if bad else 'ok   '} {short:70s} mfma loops {len(loops)}  scratch ops in hot blocks {sum(v[1] for v in loops.values())}, "
+              f"in rare blocks {sum(v[2] for v in loops.values())}  (whole kernel {total})  waterfall DMA in loops {waterfalls}")
         dirty += bool(bad)
     return 1 if dirty else 0
 

@@ -616,8 +616,9 @@ static int conv_halo_launch_t(const V3dGemmParams& p0, hipStream_t st) {
     p.mt = (int)(p.M / 192);
     p.nt = (int)(p.N / 320);
     const int ntiles = p.mt * p.nt;
-    // (stream-K tail: the last round's tiles are cut at 32-channel chunks and shared out over all CUs; at least 4 chunks per piece)
-    const int grid = v3d_sk_plan(p, ntiles, (int)(p.K / 32), 4, (size_t)192 * 320 * 4, (void*)st);
+    // (stream-K tail: the last round's tiles are cut at 32-channel chunks and shared out over all CUs; at least 4 chunks per piece and 2 chunks
+    // (18 / 6 steps) of idling removed)
+    const int grid = v3d_sk_plan(p, ntiles, (int)(p.K / 32), 4, 2, (size_t)192 * 320 * 4, (void*)st);
     const bool xf = p.gn_in != nullptr, gn = p.gn_stats != nullptr;
     if (xf && gn) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
     else if (xf) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, false>), dim3(grid), dim3(512), 0, st, p, ntiles);

@@ -918,18 +918,26 @@ std::mutex g_sk_mu;
 long long g_sk_launches = 0;
 }  // namespace
 
-int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, size_t slot_bytes, void* stream) {
+// would a launch of `ntiles` tiles of `units` granules get a stream-K tail?  Worth it when the partial round leaves >= 1/8 of the chip idle,
+// every block still gets a piece of >= min_units granules, and the idle time it removes ((G - R) / G of a tile, in granules) is >= min_saved:
+// the hand-off costs 10-15 us per owner (publish 245 KB write-through, flag, read back).
+bool v3d_sk_wanted(int ntiles, int units, int min_units, int min_saved) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V3D_STREAMK"); on = e ? atoi(e) : 1; }          // A/B knob: 0 = classic tile assignment everywhere
+    const int G = v3d_num_cus();
+    const int R = ntiles % G;
+    return on && R != 0 && (G - R) * 8 >= G && (long long)R * units / G >= min_units && (long long)(G - R) * units / G >= min_saved;
+}
+
+int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, int min_saved, size_t slot_bytes, void* stream) {
     p.sk_tail = p.sk_full = 0;
     p.sk_units = units;
     p.sk_ws = nullptr;
     p.sk_flags = nullptr;
     const int G = v3d_num_cus();
     const int classic = ntiles < G ? ntiles : G;
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("V3D_STREAMK"); on = e ? atoi(e) : 1; }          // A/B knob: 0 = classic tile assignment everywhere
     const int full = ntiles / G, R = ntiles % G;
-    // worth it when the partial round leaves >= 1/8 of the chip idle and every block still gets a piece of >= min_units granules
-    if (!on || R == 0 || (G - R) * 8 < G || (long long)R * units / G < min_units) return classic;
+    if (!v3d_sk_wanted(ntiles, units, min_units, min_saved)) return classic;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(g_sk_mu);
     const SkWorkspace* w = nullptr;

@@ -67,7 +67,8 @@ int v3d_conv_halo_variant(const V3dGemmParams& p, int mode);          // 0 = not
 int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream);
 // gemm.hip: stream-K plan of a persistent launch (fills p.sk_*, returns the grid): ntiles tiles of `units` split granules on the device's CUs;
 // slot_bytes = one block's accumulators in fp32.  Leaves the classic assignment (sk_tail = 0) when the tail round is full enough or too thin.
-int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, size_t slot_bytes, void* stream);
+int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, int min_saved, size_t slot_bytes, void* stream);
+bool v3d_sk_wanted(int ntiles, int units, int min_units, int min_saved);
 
 namespace {
 
@@ -826,7 +827,8 @@ __device__ __forceinline__ void sk_gather(const GP& p, f32x4 (&acc)[MF][NF], int
         unsigned* flag = p.sk_flags + d * 8 + wave;
         bool ok = false;
         for (int spin = 0; spin < (1 << 21); ++spin) {
-            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = true; break; }
+            // (every lane polls the same word; readfirstlane keeps the loop exit - and with it everything behind the loop - wave-uniform)
+            if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) { ok = true; break; }
             __builtin_amdgcn_s_sleep(4);
         }
         if (!ok) {
