@@ -49,7 +49,7 @@ PEAK_HBM_GBPS = 8000.0
 RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)      # 312.5: launches below it are HBM-bound (classified per launch)
 F_UNET_TFLOP = 45.677          # algorithmic FLOPs of one denoiser evaluation (reference graph, cfg batch 36)
 F_VAE_TFLOP_PER_FRAME = 3.043
-PMC_PROFILE = "r02_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
+PMC_PROFILE = "r03_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
 
 T_FRAMES, STEPS, CFG, LAT = 18, 25, 4.5, 64
 P = "v3d_amd.sgm.modules.diffusionmodules."
@@ -263,7 +263,7 @@ def measure_rooflines(step):
                  "kernels_changed_since": pmc.get("csrc_sha256_16") != csrc_digest()}
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "v3d_gemm family: gemm_kernel_v3 / v2 (conv3x3 / convt3 / linear / GEGLU launches, incl. the GroupNorm-statistics epilogue of the 3x3 convolutions) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards) + ln_proj_kernel<320> (LayerNorm + q|k|v projection)",
+    return {"bound": "mfma", "kernel": "v3d_gemm family: conv_halo_kernel (GroupNorm + SiLU + conv3x3 / conv(3,1,1) in one kernel) + gemm_kernel_v3 / v2 (conv3x3 / convt3 / linear / GEGLU launches, incl. the GroupNorm-statistics epilogue of the 3x3 convolutions) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards) + ln_proj_kernel<320> (LayerNorm + q|k|v projection)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC passes)", "traffic_profile": tinfo,
             "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2),

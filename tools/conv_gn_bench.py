@@ -97,6 +97,8 @@ def main():
     case("ct_L0_320_gnout", 320, 320, convt=(2, 18, 4096), add=True)
     case("ct_L1_640", 640, 640, convt=(2, 18, 1024), res=True, gn_out=False)
     case("ct_L2_1280", 1280, 1280, convt=(2, 18, 256), res=True, gn_out=False)
+    case("ct_L3_1280", 1280, 1280, convt=(2, 18, 64), res=True, gn_out=False)         # 48 tiles: only a stream-K tail fills the chip
+    case("ct_L3_1280_add", 1280, 1280, convt=(2, 18, 64), add=True, gn_out=False)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "conv_gn_bench.json"), "w") as f:
         json.dump(rows, f, indent=1)
