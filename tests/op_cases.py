@@ -577,7 +577,7 @@ def all_cases(full: bool = True):
             ("conv3x3_V3D_up", case_gemm, dict(M=0, N=640, K=640, mode=C3, conv=(4, 32, 32, 1, 2)), TOL_BF16),
             ("conv3x3_V3D_out4", case_gemm, dict(M=0, N=4, K=320, mode=C3, conv=(4, 64, 64, 1, 1), out_fp32=True), TOL_BF16),
             # partial last rounds of the persistent v3 kernels (192 / 384 tiles of 192 x 320 on 256 CUs).  Only the LDS-haloed convolution kernels
-            # carry a stream-K tail; in v3 the item cursor cost every launch more than the tails gained (NOTES.md 10.5) - these stay classic
+            # carry a stream-K tail: in v3 it was built twice and measured slower both times (NOTES.md 10.5) - these launches stay classic
             ("lin_V3D_L2_ffout_partial_round", case_gemm, dict(M=9216, N=1280, K=5120, res=1, expect_streamk=False, seed=31), TOL_BF16),
             ("lin_V3D_L1_ffout_partial_round", case_gemm, dict(M=36864, N=640, K=2560, res=2, expect_streamk=False, seed=32), TOL_BF16),
             ("convt3_V3D_L2_partial_round", case_gemm, dict(M=0, N=1280, K=1280, mode=CT, convt=(2, 18, 256, 0, 0, 17), res=1, add=True, expect_streamk=False, seed=34), TOL_BF16),

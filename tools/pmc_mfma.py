@@ -17,7 +17,7 @@ disp_c = "dispatch_id" if "dispatch_id" in ix else None
 
 
 def family(name):
-    for key, fam in (("ff_fused_kernel", "ff_fused"), ("ln_proj_kernel", "ln_proj"), ("gemm_kernel_v3<192, 320", "gemm_v3_192x320"), ("gemm_kernel_v3<256, 128", "gemm_v3_256x128_geglu"),
+    for key, fam in (("ff_fused_kernel", "ff_fused"), ("ln_proj_kernel", "ln_proj"), ("conv_halo_kernel<0", "conv_halo_3x3"), ("conv_halo_kernel<1", "conv_halo_temporal"), ("conv_halo_kernel", "conv_halo"), ("gemm_kernel_v3<192, 320", "gemm_v3_192x320"), ("gemm_kernel_v3<256, 128", "gemm_v3_256x128_geglu"),
                      ("gemm_kernel_v3", "gemm_v3_256x256"), ("gemm_kernel_v2", "gemm_v2"), ("gemm_kernel_v1", "gemm_v1"), ("attn_spatial", "attn_spatial"),
                      ("attn_vae", "attn_vae")):
         if key in name:

@@ -403,13 +403,13 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
         set_tap(0);
     };
     set_tile(0);
-    auto issue_piece = [&](int stage, int i) __attribute__((always_inline)) {
+    auto issue_piece = [&](int stage, int i, int so) __attribute__((always_inline)) {
         if V3D_ABL(p, 4) return;
         const int q = wave + NW * i;
         // experiment (bit 2048): activation pieces issued out of range - same DMA op count, zeros instead of an L2 fetch: what the L2->LDS bytes
         // of the activation operand cost (a lower bound of what an LDS-resident halo tile would save a 3x3 convolution)
         const unsigned vo = (V3D_ABL(p, 2048) && q < APIECES) ? kInvalid : voff[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)vo, ld_k0 * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + stage * STAGE_BYTES + q * 1024), 16, (int)vo, so, 0, 0);
     };
     auto issue_advance = [&]() __attribute__((always_inline)) {
         if (ntaps<MODE>() > 1 && p.tap_inner) {   // (k outer, tap inner), see the v2 loader
@@ -442,8 +442,12 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
         }
     };
     auto issue = [&](int stage) __attribute__((always_inline)) {
+        // the k offset is wave-uniform, but in the multi-tap modes the compiler takes it for lane-varying, keeps it in a vector register and
+        // wraps EVERY LDS-DMA issue of the main loop into a readfirstlane "waterfall" loop (rounds 1-2 shipped the 3x3 and temporal
+        // convolutions that way; tools/check_loop_scratch.py flags it now).  One explicit readfirstlane per step: conv3x3 launches -5...-9 %.
+        const int so = __builtin_amdgcn_readfirstlane(ld_k0 * 2);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) issue_piece(stage, i);
+        for (int i = 0; i < PPW; ++i) issue_piece(stage, i, so);
         issue_advance();
     };
 
