@@ -96,7 +96,11 @@ def make_step(wrapped, dec, sampler, denoiser, noise, c, uc, device, graph=False
         return denoiser(wrapped, inp, sigma, cc, **extra)
 
     def decode(z):
-        return dec(z, timesteps=frames)
+        # DiffusionEngine.decode_first_stage with en_and_decode_n_samples_a_time = decoding_t = frames (V3D_512.py:187): one sample's frames per
+        # decoder call (with --inputs 4 the 72-frame activation of the 512 x 512 level would also exceed the 4 GiB a buffer descriptor spans)
+        if z.shape[0] == frames:
+            return dec(z, timesteps=frames)
+        return torch.cat([dec(z[i:i + frames], timesteps=frames) for i in range(0, z.shape[0], frames)], dim=0)
 
     den_g = graphed(den, enabled=bool(graph))
     dec_g = graphed(decode, enabled=bool(graph))

@@ -260,6 +260,17 @@ int v3d_edm_scalings(const float* sigma, float* c_skip, float* c_out, float* c_i
  * (denoiser.py:36-37 `input * c_in`, wrappers.py:27 torch.cat((x, c["concat"]), 1), NCHW fp32 -> channels-last bf16) */
 int v3d_pack_input(const float* x, const float* scale, int64_t C1, const float* cond, int64_t C2, void* out_bf16,
                    int64_t n, int64_t S, int64_t Cpad, v3d_stream_t stream);
+/* The same assembly as the im2col of the U-Net's first convolution (openaimodel.py input_blocks[0]: conv_nd(dims, in_channels, model_channels, 3,
+ * padding=1) on 8 input channels): out_bf16[n][y][x][tap*8 + c] = packed(n, y+dy-1, x+dx-1, c), tap = dy*3+dx, zero outside the image and in the
+ * columns behind 72 (row width Kpad, a multiple of 8) - the convolution then is ONE GEMM with K = Kpad against the weight re-packed as
+ * W[o][tap*8 + c] (the implicit-GEMM kernels need K % 32 == 0 per tap: with K = 8 the launch ran on the generic kernel, 258 us for 28 MB). */
+int v3d_pack_input_im2col3x3(const float* x, const float* scale, int64_t C1, const float* cond, int64_t C2, void* out_bf16,
+                             int64_t n, int32_t H, int32_t W, int64_t Kpad, v3d_stream_t stream);
+/* 3x3 convolution with very few output channels (the U-Net's `out` conv: model_channels -> 4, openaimodel.py self.out[2]) as GEMM + gather:
+ * y fp32 [n*H*W][ldy] holds, per UNSHIFTED pixel, the nine taps' products y[m][tap*C + c] = x[m] . W[tap][c] (one GEMM with N = 9 C rows);
+ * out[m][c] = bias[c] + sum over the taps whose source pixel lies inside the image of y[m + (dy-1) W + (dx-1)][tap*C + c], fixed tap order. */
+int v3d_tapsum3x3(const float* y, int64_t ldy, const float* bias, float* out, int64_t n, int32_t H, int32_t W, int32_t C,
+                  v3d_stream_t stream);
 /* denoised[n][c][s] = net[n][s][c] * c_out[n] + x[n][c][s] * c_skip[n]   (denoiser.py:36-39; net is fp32 channels-last, ld = ldn) */
 int v3d_denoise_combine(const float* net, int64_t ldn, const float* x, const float* c_out, const float* c_skip,
                         float* out, int64_t n, int64_t C, int64_t S, v3d_stream_t stream);

@@ -277,6 +277,26 @@ class EmulOps(OpsBase):
             full = torch.cat([full, torch.zeros(n, Cpad - full.shape[1], S, device=x.device)], dim=1)
         return full.permute(0, 2, 1).reshape(n * S, Cpad).to(self.act_dtype)
 
+    def pack_input_im2col3x3(self, x, scale, cond, Kpad):
+        """v3d_pack_input_im2col3x3: the packed 8-channel input, unfolded 3x3 (tap-major columns tap*8 + c), zero-padded to Kpad columns."""
+        n, C1, H, W = x.shape
+        packed = self.pack_input(x, scale, cond, 8).float().reshape(n, H, W, 8).permute(0, 3, 1, 2)      # bf16-rounded, like the kernel's lanes
+        cols = torch.nn.functional.unfold(packed, 3, padding=1).reshape(n, 8, 9, H * W)                  # [n, c, tap, s]
+        out = torch.zeros(n, H * W, Kpad, device=x.device)
+        out[:, :, :72] = cols.permute(0, 3, 2, 1).reshape(n, H * W, 72)
+        return out.reshape(n * H * W, Kpad).to(self.act_dtype)
+
+    def tapsum3x3(self, y, bias, n, H, W, C):
+        """v3d_tapsum3x3: gather-sum of the nine taps' products (fp32, fixed tap order)."""
+        yv = y.float()[:, :9 * C].reshape(n, H, W, 9, C)
+        out = torch.zeros(n, H, W, C, device=y.device) if bias is None else bias.float().reshape(1, 1, 1, C).expand(n, H, W, C).clone()
+        for tap in range(9):
+            dy, dx = tap // 3 - 1, tap % 3 - 1
+            ys, ye = max(0, -dy), min(H, H - dy)
+            xs, xe = max(0, -dx), min(W, W - dx)
+            out[:, ys:ye, xs:xe] += yv[:, ys + dy:ye + dy, xs + dx:xe + dx, tap]
+        return out.reshape(n * H * W, C)
+
     def denoise_combine(self, net, x, c_out, c_skip):
         n, C = x.shape[0], x.shape[1]
         S = x.numel() // (n * C)

@@ -419,6 +419,26 @@ def case_elementwise(hip, emu, dev, seed=0):
     sc = _rand(g, (n,), F32, 1.0, dev)
     res["pack_input"] = compare(hip.pack_input(x, sc, cond, 8), emu.pack_input(x, sc, cond, 8))
     res["pack_input_pad"] = compare(hip.pack_input(x, None, None, 8), emu.pack_input(x, None, None, 8))
+    # the U-Net's first / last convolution as GEMMs: unfolded packed input, gather-sum of the nine taps' products; and, end to end, the two
+    # forms of each convolution against the implicit-GEMM launch they replace
+    res["pack_input_im2col"] = compare(hip.pack_input_im2col3x3(x, sc, cond, 96), emu.pack_input_im2col3x3(x, sc, cond, 96))
+    res["pack_input_im2col_nocond"] = compare(hip.pack_input_im2col3x3(x, None, None, 96), emu.pack_input_im2col3x3(x, None, None, 96))
+    yt = _rand(g, (n * H * W, 64), F32, 1.0, dev)
+    bt = _rand(g, (4,), F32, 1.0, dev)
+    res["tapsum3x3"] = compare(hip.tapsum3x3(yt, bt, n, H, W, 4), emu.tapsum3x3(yt, bt, n, H, W, 4))
+    res["tapsum3x3_nobias_c3"] = compare(hip.tapsum3x3(yt[:, :27], None, n, H, W, 3), emu.tapsum3x3(yt[:, :27], None, n, H, W, 3))
+    w_in = _rand(g, (9, 32, 8), scale=0.3, device=dev)                      # [tap][O][I]
+    b_in = _rand(g, (32,), F32, 0.5, dev)
+    w96 = torch.zeros(32, 96, dtype=BF, device=dev)
+    w96[:, :72] = w_in.permute(1, 0, 2).reshape(32, 72)
+    direct = hip.conv3x3(hip.pack_input(x, sc, cond, 8), w_in, b_in, n, H, W)
+    res["conv_in_as_gemm"] = compare(hip.linear(hip.pack_input_im2col3x3(x, sc, cond, 96), w96, b_in), direct)
+    xo = _rand(g, (n * H * W, 64), device=dev)
+    w_out = _rand(g, (9, 4, 64), scale=0.1, device=dev)
+    w36 = torch.zeros(64, 64, dtype=BF, device=dev)
+    w36[:36] = w_out.reshape(36, 64)
+    direct = hip.conv3x3(xo, w_out, bt, n, H, W, out_dtype=F32)
+    res["conv_out_as_gemm"] = compare(hip.tapsum3x3(hip.linear(xo, w36, None, out_dtype=F32), bt, n, H, W, 4), direct)
     net = _rand(g, (n * H * W, 4), F32, 1.0, dev)
     res["denoise_combine"] = compare(hip.denoise_combine(net, x, sc, t), emu.denoise_combine(net, x, sc, t))
     scale = _rand(g, (T,), F32, 1.0, dev) + 3

@@ -65,6 +65,55 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+// im2col of the packed input for the U-Net's first convolution: out[img][y][x][tap * Cpad + c] = packed(img, y + dy - 1, x + dx - 1, c), tap = dy * 3 + dx,
+// zero outside the image and in the padding columns (row width Kpad >= 9 * Cpad).  One 16-byte store (8 channels of one tap) per thread.
+__global__ void pack_input_im2col_kernel(const float* __restrict__ x, const float* __restrict__ scale, int C1, const float* __restrict__ cond, int C2,
+                                         bf16_t* __restrict__ out, long long n, int H, int W, int Kpad) {
+    const int vec_per_row = Kpad / 8;
+    const long long S = (long long)H * W, total = n * S * vec_per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vec_per_row);              // vector v = tap (Cpad == 8) or padding
+        const long long rs = i / vec_per_row;
+        const long long s = rs % S, img = rs / S;
+        const int y = (int)(s / W) + v / 3 - 1, xx = (int)(s % W) + v % 3 - 1;
+        float f[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] = 0.f;
+        if (v < 9 && y >= 0 && y < H && xx >= 0 && xx < W) {
+            const long long sp = (long long)y * W + xx;
+            const float sc = scale ? scale[img] : 1.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < C1) f[c] = x[(img * C1 + c) * S + sp] * sc;
+                else if (c < C1 + C2) f[c] = cond[(img * C2 + (c - C1)) * S + sp];
+            }
+        }
+        u32x4 o;
+        o[0] = pack2bf(f[0], f[1]); o[1] = pack2bf(f[2], f[3]); o[2] = pack2bf(f[4], f[5]); o[3] = pack2bf(f[6], f[7]);
+        *reinterpret_cast<u32x4*>(out + rs * Kpad + v * 8) = o;
+    }
+}
+
+// 3x3 convolution with very few output channels as GEMM + gather: y[m][tap * C + c] holds the tap's product at the UNSHIFTED pixel m;
+// out[m][c] = bias[c] + sum over taps whose source pixel (y + dy - 1, x + dx - 1) lies inside the image of y[that pixel][tap * C + c]
+__global__ void tapsum3x3_kernel(const float* __restrict__ yv, long long ldy, const float* __restrict__ bias, float* __restrict__ out, long long n, int H,
+                                 int W, int C) {
+    const long long S = (long long)H * W, total = n * S * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long m = i / C;
+        const long long s = m % S;
+        const int y0 = (int)(s / W), x0 = (int)(s % W);
+        float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {          // (fixed order: deterministic)
+            const int y = y0 + tap / 3 - 1, xx = x0 + tap % 3 - 1;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) acc += yv[(m + (long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * ldy + tap * C + c];
+        }
+        out[i] = acc;
+    }
+}
+
 __global__ void denoise_combine_kernel(const float* __restrict__ net, long long ldn, const float* __restrict__ x,
                                        const float* __restrict__ c_out, const float* __restrict__ c_skip,
                                        float* __restrict__ out, long long n, long long C, long long S) {
@@ -318,6 +367,22 @@ extern "C" int v3d_pack_input(const float* x, const float* scale, int64_t C1, co
     hipLaunchKernelGGL(pack_input_kernel, dim3(nblocks(n * S * Cpad)), dim3(256), 0, ST, x, scale, (long long)C1, cond, (long long)C2,
                        (bf16_t*)out_bf16, (long long)n, (long long)S, (long long)Cpad);
     return v3d_check_launch("v3d_pack_input");
+}
+
+extern "C" int v3d_pack_input_im2col3x3(const float* x, const float* scale, int64_t C1, const float* cond, int64_t C2, void* out_bf16, int64_t n,
+                                        int32_t H, int32_t W, int64_t Kpad, v3d_stream_t stream) {
+    V3D_REQUIRE(x && out_bf16 && n > 0 && H > 0 && W > 0 && C1 > 0 && C1 + C2 <= 8, "v3d_pack_input_im2col3x3: bad args (at most 8 input channels)");
+    V3D_REQUIRE((C2 == 0) == (cond == nullptr), "v3d_pack_input_im2col3x3: cond/C2 mismatch");
+    V3D_REQUIRE(Kpad >= 72 && Kpad % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0, "v3d_pack_input_im2col3x3: Kpad must be a multiple of 8 and >= 72, out 16-byte aligned");
+    hipLaunchKernelGGL(pack_input_im2col_kernel, dim3(nblocks(n * H * W * (Kpad / 8))), dim3(256), 0, ST, x, scale, (int)C1, cond, (int)C2, (bf16_t*)out_bf16,
+                       (long long)n, (int)H, (int)W, (int)Kpad);
+    return v3d_check_launch("v3d_pack_input_im2col3x3");
+}
+
+extern "C" int v3d_tapsum3x3(const float* y, int64_t ldy, const float* bias, float* out, int64_t n, int32_t H, int32_t W, int32_t C, v3d_stream_t stream) {
+    V3D_REQUIRE(y && out && n > 0 && H > 0 && W > 0 && C > 0 && ldy >= 9 * C, "v3d_tapsum3x3: bad args (ldy >= 9 C)");
+    hipLaunchKernelGGL(tapsum3x3_kernel, dim3(nblocks(n * H * W * C)), dim3(256), 0, ST, y, (long long)ldy, bias, out, (long long)n, (int)H, (int)W, (int)C);
+    return v3d_check_launch("v3d_tapsum3x3");
 }
 
 extern "C" int v3d_denoise_combine(const float* net, int64_t ldn, const float* x, const float* c_out, const float* c_skip,

@@ -54,6 +54,27 @@ def pack_conv3x3(conv: nn.Conv2d):
     return _bf(w.permute(2, 3, 0, 1).reshape(9, O, Ip)), (None if conv.bias is None else _f(conv.bias))
 
 
+def pack_conv3x3_im2col(conv: nn.Conv2d, Kpad=96):
+    """First convolution of the U-Net (8 input channels) as ONE GEMM over the unfolded input (v3d_pack_input_im2col3x3):
+    W[o][tap * 8 + c], zero-padded to Kpad columns."""
+    w = conv.weight.detach()                      # [O, I, 3, 3]
+    O, I = w.shape[0], w.shape[1]
+    assert I <= 8 and Kpad >= 72
+    wp = w.new_zeros(O, Kpad)
+    wp.view(O, Kpad)[:, :72].view(O, 9, 8)[:, :, :I] = w.permute(0, 2, 3, 1).reshape(O, 9, I)
+    return _bf(wp), (None if conv.bias is None else _f(conv.bias))
+
+
+def pack_conv3x3_taps(conv: nn.Conv2d, Npad=64):
+    """Last convolution of the U-Net (4 output channels) as GEMM + gather (v3d_tapsum3x3): rows tap * O + o of ONE [Npad, I] weight."""
+    w = conv.weight.detach()                      # [O, I, 3, 3]
+    O, I = w.shape[0], w.shape[1]
+    assert 9 * O <= Npad
+    wp = w.new_zeros(Npad, I)
+    wp[:9 * O] = w.permute(2, 3, 0, 1).reshape(9 * O, I)
+    return _bf(wp), (None if conv.bias is None else _f(conv.bias))
+
+
 def pack_convt3(conv: nn.Conv3d):
     w = conv.weight.detach()                      # [O, I, 3, 1, 1]
     O, I = w.shape[0], w.shape[1]
@@ -234,6 +255,8 @@ class UNetPack:
     mix_alpha: torch.Tensor
     mix_kind: torch.Tensor
     uses_ioi: bool
+    conv_in_gemm: Optional[tuple] = None      # (W [model_channels, 96] over the unfolded 8-channel input, bias): v3d_pack_input_im2col3x3 + ONE GEMM
+    out_conv_taps: Optional[tuple] = None     # (W [64, model_channels] rows tap * out_ch + o, bias): ONE GEMM + v3d_tapsum3x3
 
 
 def _pack_ff(ff, norm=None) -> FFPack:
@@ -378,6 +401,8 @@ def pack_unet(net) -> UNetPack:
         out_channels=net.out_channels, context_dim=net.context_dim, adm_in=adm_in, time_embed=time_embed, label_emb=label,
         conv_in=conv_in, input_stages=input_stages, middle=middle, output_stages=output_stages,
         out_norm=pack_norm(net.out[0]), out_conv=pack_conv3x3(net.out[2]),
+        conv_in_gemm=pack_conv3x3_im2col(net.input_blocks[0][0]) if net.in_channels <= 8 else None,
+        out_conv_taps=pack_conv3x3_taps(net.out[2]) if 9 * net.out_channels <= 64 else None,
         emb_w=_bf(torch.cat(col.emb_w, 0)), emb_b=_f(torch.cat(col.emb_b, 0)),
         ctx_w=_bf(torch.cat(col.ctx_w, 0)), ctx_b=_f(torch.cat(col.ctx_b, 0)),
         mix_alpha=torch.tensor(col.alphas, dtype=F32, device=dev), mix_kind=torch.tensor(col.kinds, dtype=torch.int32, device=dev),

@@ -204,13 +204,19 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
     coefs = ops.blend_coefs(pk.mix_alpha, pk.mix_kind, ioi, n)
     env = Env(ops=ops, emb_all=emb_all, ctx_all=ctx_all, coefs=coefs, shard=shard)
 
-    h = ops.pack_input(x.float().contiguous(), scale, None if concat is None else concat.float().contiguous(), pk.in_pad)
+    # first convolution (8 input channels): the packed input leaves its assembly kernel already unfolded 3x3 and the convolution is ONE GEMM
+    # with K = 96 (per tap K = 8 is below every MFMA kernel's granule: the implicit-GEMM launch ran on the generic kernel, 258 us)
+    in_gemm = pk.conv_in_gemm is not None and x.dim() == 4 and os.environ.get("V3D_CONV_IO_GEMM", "1") != "0"
+    if in_gemm:
+        h = ops.pack_input_im2col3x3(x.float().contiguous(), scale, None if concat is None else concat.float().contiguous(), pk.conv_in_gemm[0].shape[-1])
+    else:
+        h = ops.pack_input(x.float().contiguous(), scale, None if concat is None else concat.float().contiguous(), pk.in_pad)
     g = Geo(n=n, B=B, T=T, H=H, W=W)
 
     def run_stage(items, h, g, skip=None):
         for kind, p in items:
             if kind == "conv_in":
-                h = ops.conv3x3(h, p[0], p[1], g.n, g.H, g.W)
+                h = ops.linear(h, pk.conv_in_gemm[0], pk.conv_in_gemm[1]) if in_gemm else ops.conv3x3(h, p[0], p[1], g.n, g.H, g.W)
             elif kind == "res":
                 h = unet_resblock(env, g, p, h, skip)
                 skip = None
@@ -235,5 +241,11 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
         h, g = run_stage(items, h, g, skip=hs.pop())      # th.cat([h, hs.pop()], 1) is consumed split, never built
     ga, be, eps = pk.out_norm
     h = ops.groupnorm(h, None, ga, be, g.n, g.S, eps=eps, silu=True)
-    out = ops.conv3x3(h, pk.out_conv[0], pk.out_conv[1], g.n, g.H, g.W, out_dtype=F32)     # [n*S, out_ch] fp32
+    if pk.out_conv_taps is not None and os.environ.get("V3D_CONV_IO_GEMM", "1") != "0":
+        # last convolution (4 output channels): ONE GEMM with the nine taps' 36 weight rows on the unshifted pixels, then the taps' products are
+        # gathered per pixel (N = 4 is below every MFMA kernel's tile: the implicit-GEMM launch ran on the generic kernel, 162 us)
+        y = ops.linear(h, pk.out_conv_taps[0], None, out_dtype=F32)
+        out = ops.tapsum3x3(y, pk.out_conv_taps[1], g.n, g.H, g.W, pk.out_channels)         # [n*S, out_ch] fp32
+    else:
+        out = ops.conv3x3(h, pk.out_conv[0], pk.out_conv[1], g.n, g.H, g.W, out_dtype=F32)     # [n*S, out_ch] fp32
     return out.view(n, g.H, g.W, pk.out_channels).permute(0, 3, 1, 2)

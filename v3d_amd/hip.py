@@ -73,6 +73,8 @@ SIGNATURES = {
     "v3d_silu_add": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "v3d_edm_scalings": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "v3d_pack_input": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "v3d_pack_input_im2col3x3": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i64, c_vp]),
+    "v3d_tapsum3x3": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "v3d_denoise_combine": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "v3d_cfg_combine": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "v3d_euler_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
@@ -415,6 +417,31 @@ class HipOps(OpsBase):
         out = self.empty((n * S, Cpad), torch.bfloat16, x.device)
         self._check(self.lib.v3d_pack_input(x.data_ptr(), _ptr(scale), C1, _ptr(cond), C2, out.data_ptr(), n, S, Cpad, self._stream()),
                     "v3d_pack_input")
+        return out
+
+    def pack_input_im2col3x3(self, x, scale, cond, Kpad):
+        f32 = torch.float32
+        self._req_c(x, f32, "im2col.x")
+        n, C1, H, W = x.shape
+        C2 = 0
+        if cond is not None:
+            self._req_c(cond, f32, "im2col.cond")
+            C2 = cond.shape[1]
+        if scale is not None:
+            self._req_c(scale, f32, "im2col.scale")
+        out = self.empty((n * H * W, Kpad), torch.bfloat16, x.device)
+        self._check(self.lib.v3d_pack_input_im2col3x3(x.data_ptr(), _ptr(scale), C1, _ptr(cond), C2, out.data_ptr(), n, H, W, Kpad, self._stream()),
+                    "v3d_pack_input_im2col3x3")
+        return out
+
+    def tapsum3x3(self, y, bias, n, H, W, C):
+        f32 = torch.float32
+        self._req(y, f32, "tapsum.y")
+        assert y.shape[0] == n * H * W and y.stride(-1) == 1
+        if bias is not None:
+            self._req_c(bias, f32, "tapsum.bias")
+        out = self.empty((n * H * W, C), f32, y.device)
+        self._check(self.lib.v3d_tapsum3x3(y.data_ptr(), y.stride(0), _ptr(bias), out.data_ptr(), n, H, W, C, self._stream()), "v3d_tapsum3x3")
         return out
 
     def denoise_combine(self, net, x, c_out, c_skip):
