@@ -969,6 +969,25 @@ int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, int min_
     return G;
 }
 
+// tests only (CPU): the work list block b of a G-block launch would build for `ntiles` tiles of `units` granules - the device code's own table
+// (gemm_common.h sk_build_table), so the decomposition can be checked for every shape without a GPU.  out[12]: items, donor flag, then two
+// pieces of (tile, u0, u1, role, d0, d1) - the table's layout without its padding.  Returns 0 when no tail is planned for this launch.
+extern "C" int v3d_debug_sk_table(int ntiles, int units, int G, int b, int min_units, int min_saved, int* out) {
+    const int R = ntiles % G;
+    if (R == 0 || (G - R) * 8 < G || (long long)R * units / G < min_units || (long long)(G - R) * units / G < min_saved) return 0;
+    V3dGemmParams p = {};
+    p.sk_tail = R;
+    p.sk_full = ntiles / G;
+    p.sk_units = units;
+    int tab[SK_TAB_BYTES / 4] = {0};
+    sk_build_table(p, b, G, ntiles, units, tab);
+    out[0] = tab[0];
+    out[1] = tab[1];
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 6; ++j) out[2 + 6 * k + j] = tab[4 + 8 * k + j];
+    return 1;
+}
+
 // tests only: launches planned with a stream-K tail; hand-offs that gave up waiting (must stay 0)
 extern "C" long long v3d_debug_sk_launches(void) { return g_sk_launches; }
 extern "C" long long v3d_debug_sk_timeouts(void) {

@@ -751,7 +751,7 @@ struct SkItem {
 // U = granules per tile as the KERNEL counts them (the host planned with the same number).
 // tab[0] = items of the block, tab[1] = 1 if item 0 is a donor piece, tab[4 + 8 k ..] = its k-th piece of the last round (k < 2).
 constexpr int SK_TAB_BYTES = 96;
-__device__ __forceinline__ void sk_build_table(const GP& p, int b, int G, int ntiles, int U, int* tab) {
+__host__ __device__ __forceinline__ void sk_build_table(const GP& p, int b, int G, int ntiles, int U, int* tab) {
     tab[1] = 0;
     if (p.sk_tail == 0) {
         tab[0] = (ntiles - b + G - 1) / G;
