@@ -191,6 +191,15 @@ int v3d_groupnorm_finalize(const float* stats, int64_t nslots, double* sums, int
 int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* table, void* out,
                         int64_t n_img, int64_t S, int64_t imgs_per_stat, int32_t silu, v3d_stream_t stream);
 
+/* GroupNorm (+SiLU) of SMALL statistics groups in ONE launch (the 8 x 8 level of the U-Net, the 16 x 16 level's transformer norms: the
+ * three-step form is launch-bound there): a block keeps (statistics group, 1..8 channel groups) in registers, reduces in a fixed order,
+ * normalises what it holds.  Same result contract as stats -> finalize -> apply (fp64 sums, scale = gamma rstd, shift = beta - mean scale,
+ * bf16 out); deterministic.  v3d_groupnorm_small_supported: 32 groups of a multiple of 8 channels and imgs_per_stat * S * (channels of the
+ * block's groups) <= 49152 elements with row segments >= 64 bytes; anything else is refused (use the three-step form). */
+int v3d_groupnorm_small_supported(int64_t C1, int64_t C2, int64_t S, int32_t groups, int64_t imgs_per_stat);
+int v3d_groupnorm_small(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* gamma, const float* beta, void* out,
+                        int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, float eps, int32_t silu, v3d_stream_t stream);
+
 /* LayerNorm over the last dim of bf16 [M][C]; optional fp32 row-group vector added first:
  *   xs = x + add[(m / add_rpg) * add_ld + c];  if xsum_out: xsum_out[m] = bf16(xs);  out = LN(xs)*gamma + beta
  * replaces nn.LayerNorm (attention.py:525-527; video_attention.py:51,79,93-94) and the frame-position add

@@ -156,6 +156,36 @@ class EmulOps(OpsBase):
         sh = beta.double()[None, :] - mean.repeat_interleave(C // groups, dim=1) * sc
         table.copy_(torch.stack([sc, sh], dim=-1).float())
 
+    def groupnorm_small_supported(self, C1, C2, S, imgs_per_stat=1, groups=32):
+        """Mirror of v3d_groupnorm_small_supported (norm.hip gn_small_groups): so the engine takes the same path on the emulator."""
+        C, rows = C1 + C2, imgs_per_stat * S
+        if groups != 32 or C % 32 or C1 % 8 or rows <= 0 or (C // 32) % 8:
+            return False
+        cpg = C // 32
+        for gb in (8, 4, 2, 1):
+            if C2 and C1 % (gb * cpg):
+                continue
+            if rows * (gb * cpg // 8) <= 256 * 24 and gb * cpg * 2 >= 64:
+                return True
+        return False
+
+    def groupnorm_small(self, x1, x2, gamma, beta, out, n_img, S, *, eps, silu, imgs_per_stat=1, groups=32):
+        """v3d_groupnorm_small: statistics in fp64 over the statistics group, y = x * (gamma rstd) + (beta - mean gamma rstd), SiLU, bf16."""
+        x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
+        C = x.shape[-1]
+        n_stat, rows, cpg = n_img // imgs_per_stat, imgs_per_stat * S, C // groups
+        v = x.reshape(n_stat, rows, groups, cpg).double()
+        mean = v.mean(dim=(1, 3), keepdim=True)
+        var = ((v * v).mean(dim=(1, 3), keepdim=True) - mean * mean).clamp_min(0.0)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        sc = gamma.float().reshape(1, 1, groups, cpg) * rstd.float()
+        sh = beta.float().reshape(1, 1, groups, cpg) - mean.float() * sc
+        y = v.float() * sc + sh
+        if silu:
+            y = y * torch.sigmoid(y)
+        out.copy_(y.reshape(n_img * S, C).to(out.dtype))
+        return out
+
     def groupnorm_apply(self, x1, x2, table, out, n_img, S, imgs_per_stat, silu):
         x = self._cat(x1, x2).float()
         C = x.shape[-1]

@@ -34,6 +34,41 @@ def compare(a: torch.Tensor, b: torch.Tensor):
 
 
 # ------------------------------------------------------------------------------------------------
+def case_groupnorm_small(hip, emu, dev, *, n_img, S, C1, C2=0, imgs_per_stat=1, silu=True, seed=0, supported=True, mean=0.5):
+    """v3d_groupnorm_small (one launch: statistics + normalisation of small statistics groups) against fp64 F.group_norm, against the
+    three-step form on the same input (same result contract: both round scale / shift alike -> at most a bf16 ulp apart), and bit-equal
+    to itself on a second launch."""
+    g = torch.Generator().manual_seed(seed)
+    C = C1 + C2
+    assert hip.groupnorm_small_supported(C1, C2, S, imgs_per_stat) == supported == emu.groupnorm_small_supported(C1, C2, S, imgs_per_stat)
+    if not supported:
+        return 0.0, 1.0
+    off = (torch.rand((C,), generator=g) * 2 - 1) * mean
+    x1 = (_rand(g, (n_img * S, C1), F32, 1.0, dev) + off[:C1].to(dev)).to(BF)
+    x2 = (_rand(g, (n_img * S, C2), F32, 1.3, dev) + off[C1:].to(dev)).to(BF) if C2 else None
+    gamma, beta = _rand(g, (C,), F32, 0.3, dev) + 1.0, _rand(g, (C,), F32, 0.3, dev)
+    out = torch.zeros((n_img * S, C), dtype=BF, device=dev)
+    hip.groupnorm_small(x1, x2, gamma, beta, out, n_img, S, eps=1e-5, silu=silu, imgs_per_stat=imgs_per_stat)
+    again = torch.zeros_like(out)
+    hip.groupnorm_small(x1, x2, gamma, beta, again, n_img, S, eps=1e-5, silu=silu, imgs_per_stat=imgs_per_stat)
+    assert torch.equal(out, again), "two identical launches differ"
+    x = x1.double() if x2 is None else torch.cat([x1.double(), x2.double()], dim=-1)
+    n_stat, rows = n_img // imgs_per_stat, imgs_per_stat * S
+    ref = torch.nn.functional.group_norm(x.reshape(n_stat, rows, C).permute(0, 2, 1), 32, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1).reshape(n_img * S, C)
+    if silu:
+        ref = ref * torch.sigmoid(ref)
+    table = hip.groupnorm_table(x1, x2, gamma, beta, n_img, S, eps=1e-5, imgs_per_stat=imgs_per_stat)
+    three = torch.zeros_like(out)
+    hip.groupnorm_apply(x1, x2, table, three, n_img, S, imgs_per_stat, silu)
+    r3, _ = compare(out, three)
+    assert r3 <= 1e-2, f"one-launch form vs statistics -> finalize -> apply: {r3:.3e}"
+    emu_out = torch.zeros_like(out)
+    emu.groupnorm_small(x1, x2, gamma, beta, emu_out, n_img, S, eps=1e-5, silu=silu, imgs_per_stat=imgs_per_stat)
+    re_, _ = compare(out, emu_out)
+    assert re_ <= 1e-2, f"one-launch form vs its emulation: {re_:.3e}"
+    return compare(out, ref.float())
+
+
 def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=True, add=False, res=0, coef=False,
               out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0, gn_rps=0, expect_streamk=None):
     """gn_rps > 0: the launch also gathers the GroupNorm partial sums of its output (GemmCall.gn_stats, 32 groups, gn_rps rows per statistics
@@ -522,6 +557,16 @@ def all_cases(full: bool = True):
         ("gn2d_offcentre_100", case_groupnorm, dict(n_img=2, S=1024, C1=640, mean=100.0, seed=12), TOL_BF16),
         ("gn3d_offcentre_100", case_groupnorm, dict(n_img=6, S=256, C1=320, imgs_per_stat=3, mean=100.0, std=0.5, seed=13), TOL_BF16),
         # GroupNorm + SiLU in the operand path of the LDS-haloed convolutions (conv.hip)
+        # one-launch GroupNorm of small statistics groups: the 8 x 8 level (2-D, two-source 2-D, 3-D over 18 frames), the 16 x 16 level's 2-D norm,
+        # off-centre channels, and shapes it must refuse (3-D at 16 x 16: 4608 rows; 20 channels per group)
+        ("gn_small_2d_L3", case_groupnorm_small, dict(n_img=36, S=64, C1=1280), TOL_BF16),
+        ("gn_small_2d_L3_concat", case_groupnorm_small, dict(n_img=36, S=64, C1=1280, C2=1280, seed=1), TOL_BF16),
+        ("gn_small_3d_L3", case_groupnorm_small, dict(n_img=36, S=64, C1=1280, imgs_per_stat=18, seed=2), TOL_BF16),
+        ("gn_small_2d_L2_nosilu", case_groupnorm_small, dict(n_img=36, S=256, C1=1280, silu=False, seed=3), TOL_BF16),
+        ("gn_small_offcentre", case_groupnorm_small, dict(n_img=4, S=64, C1=1280, mean=30.0, seed=4), TOL_BF16),
+        ("gn_small_odd_rows", case_groupnorm_small, dict(n_img=3, S=35, C1=256, seed=5), TOL_BF16),
+        ("gn_small_refused_3d_L2", case_groupnorm_small, dict(n_img=36, S=256, C1=1280, imgs_per_stat=18, supported=False), TOL_BF16),
+        ("gn_small_refused_cpg20", case_groupnorm_small, dict(n_img=36, S=64, C1=640, supported=False), TOL_BF16),
         ("conv_gn_64_plain", case_conv_gn, dict(N=320, C1=320, conv=(3, 64, 64)), TOL_BF16),
         ("conv_gn_64_straddle_add_gnout", case_conv_gn, dict(N=320, C1=64, conv=(6, 64, 64), add=True, gn_out=True, seed=1), TOL_BF16),
         ("conv_gn_64_concat_res", case_conv_gn, dict(N=320, C1=64, C2=32, conv=(3, 64, 64), res=1, seed=2), TOL_BF16),

@@ -468,6 +468,149 @@ extern "C" int v3d_groupnorm_apply(const void* x1, int64_t C1, const void* x2, i
     return v3d_check_launch("v3d_groupnorm_apply");
 }
 
+// ---- GroupNorm of a SMALL statistics group in one launch ---------------------------------------------------------------------------------
+// The 8 x 8 level of the U-Net (and the 16 x 16 level's transformer norms) ran three launches per GroupNorm - statistics 8-12 us, finalize
+// 7 us, apply 7-13 us, two kernel boundaries - on tensors of 6-24 MB: launch-bound.  Here a block owns (statistics group, GB channel
+// groups): it loads its slice once into registers (<= NVT 16-byte vectors per thread), reduces (sum, sumsq) per channel group in a fixed
+// order (vector partials -> LDS -> one wave per group, lane partials added in lane order by a shuffle tree), and normalises what it holds.
+// Deterministic like the three-step form; same arithmetic for the output (x * scale + shift, SiLU, bf16) with scale / shift from fp64 sums.
+template <int NVT>
+__global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x1, long long C1, const bf16_t* __restrict__ x2, long long C2,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                       long long rows, int cpg, int GB, float eps, int silu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gn_small_lds[];
+    float2* part = reinterpret_cast<float2*>(gn_small_lds);                       // [rows * VB] per-vector (sum, sumsq)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long C = C1 + C2;
+    const int VB = GB * cpg / 8;                                                  // vectors per row of the block's channel slice
+    const int vpg = cpg / 8;                                                      // vectors per channel group and row
+    const long long row0 = (long long)blockIdx.y * rows;
+    const int c0 = blockIdx.x * GB * cpg;
+    const int NV = (int)rows * VB;
+    float2* scsh = part + NV;                                                     // [GB * cpg] (scale, shift) of the block's channels
+    float2* gstat = scsh + GB * cpg;                                              // [GB] (mean, rstd)
+    uint4 v[NVT];
+    // vector i of the block = (row i / VB, column i % VB); a thread's vectors are 256 apart: (r, vc) advance by constant steps - no division
+    // per vector (the runtime divisors cost ~30 instructions each, more than the arithmetic they index)
+    const int dr = 256 / VB, dc = 256 - dr * VB;
+    int r = tid / VB, vc = tid - r * VB;
+    const int r_first = r, vc_first = vc;
+    // all loads first (vectors past the slice re-read its first vector: no branch between the loads, NVT of them in flight per thread)
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+        const bool ok = tid + 256 * k < NV;
+        v[k] = load_vec2(x1, C1, x2, C2, row0 + (ok ? r : 0), c0 + (ok ? vc : 0) * 8);
+        r += dr; vc += dc;
+        if (vc >= VB) { vc -= VB; ++r; }
+    }
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < NV) {
+            float f[8];
+            unpack8(v[k], f);
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sm += f[e]; sq += f[e] * f[e]; }
+            part[i] = make_float2(sm, sq);
+        }
+    }
+    __syncthreads();
+    // group g of the block: vectors (row, g * vpg + j), j < vpg; wave w reduces groups w, w + 4, ...: a lane walks rows lane, lane + 64, ...
+    // (fixed order), the 64 lane partials meet in a shuffle tree
+    for (int g = wave; g < GB; g += 4) {
+        double sm = 0.0, sq = 0.0;
+        for (int rr = lane; rr < (int)rows; rr += 64) {
+            const float2* pr = part + rr * VB + g * vpg;
+            for (int j = 0; j < vpg; ++j) {
+                sm += (double)pr[j].x;
+                sq += (double)pr[j].y;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            sm += __shfl_xor(sm, o, 64);
+            sq += __shfl_xor(sq, o, 64);
+        }
+        if (lane == 0) {
+            const double cnt = (double)rows * cpg;
+            const double mean = sm / cnt;
+            double var = sq / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gstat[g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+        }
+    }
+    __syncthreads();
+    // the table form of v3d_groupnorm_finalize, once per channel of the block: scale = gamma rstd, shift = beta - mean scale
+    for (int c = tid; c < GB * cpg; c += 256) {
+        const float2 ms = gstat[c / cpg];
+        const float sc = gamma[c0 + c] * ms.y;
+        scsh[c] = make_float2(sc, beta[c0 + c] - ms.x * sc);
+    }
+    __syncthreads();
+    r = r_first; vc = vc_first;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < NV) {
+            float f[8];
+            unpack8(v[k], f);
+            const float4* t = reinterpret_cast<const float4*>(scsh + vc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float4 q = t[e / 2];                         // (scale, shift) of channels e, e + 1
+                const float y0 = f[e] * q.x + q.y, y1 = f[e + 1] * q.z + q.w;
+                f[e] = silu ? silu_f(y0) : y0;
+                f[e + 1] = silu ? silu_f(y1) : y1;
+            }
+            *reinterpret_cast<uint4*>(out + (row0 + r) * C + c0 + vc * 8) = make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+        }
+        r += dr; vc += dc;
+        if (vc >= VB) { vc -= VB; ++r; }
+    }
+}
+
+// channel groups per block for the one-launch form, 0 = the tensor does not fit it (the caller keeps statistics -> finalize -> apply)
+static int gn_small_groups(long long rows, long long C1, long long C2, int groups) {
+    const long long C = C1 + C2;
+    if (groups != 32 || C % 32 || C1 % 8 || rows <= 0) return 0;
+    const long long cpg = C / 32;
+    if (cpg % 8) return 0;                                        // a 16-byte vector must lie inside one channel group
+    for (int gb = 8; gb >= 1; gb >>= 1) {
+        if (C1 % (gb * cpg) && C2) continue;                      // a block's slice must lie inside one source
+        if (rows * (gb * cpg / 8) <= 256 * 24 && gb * cpg * 2 >= 64) return gb;
+    }
+    return 0;
+}
+
+extern "C" int v3d_groupnorm_small_supported(int64_t C1, int64_t C2, int64_t S, int32_t groups, int64_t imgs_per_stat) {
+    return gn_small_groups(imgs_per_stat * S, C1, C2, groups) > 0;
+}
+
+extern "C" int v3d_groupnorm_small(const void* x1, int64_t C1, const void* x2, int64_t C2, const float* gamma, const float* beta, void* out,
+                                   int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, float eps, int32_t silu, v3d_stream_t stream) {
+    int rc = gn_check("v3d_groupnorm_small", x1, C1, x2, C2, n_img, S, groups);
+    if (rc) return rc;
+    V3D_REQUIRE(gamma && beta && out, "v3d_groupnorm_small: null pointer");
+    V3D_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0, "v3d_groupnorm_small: gamma / beta / out must be 16-byte aligned");
+    V3D_REQUIRE(imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_small: bad imgs_per_stat");
+    const long long rows = imgs_per_stat * S;
+    const int gb = gn_small_groups(rows, C1, C2, groups);
+    V3D_REQUIRE(gb > 0, "v3d_groupnorm_small: this tensor does not fit the one-launch form (v3d_groupnorm_small_supported)");
+    const int cpg = (int)((C1 + C2) / 32);
+    const long long nv = rows * (gb * cpg / 8);
+    const size_t lds = (size_t)nv * 8 + (size_t)gb * cpg * 8 + 64;
+    dim3 grid((unsigned)(32 / gb), (unsigned)(n_img / imgs_per_stat));
+#define V3D_GNS_LAUNCH(NVT_)                                                                                                                    \
+    hipLaunchKernelGGL((gn_small_kernel<NVT_>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1, (const bf16_t*)x2,     \
+                       (long long)C2, gamma, beta, (bf16_t*)out, rows, cpg, gb, eps, silu)
+    if (nv <= 256 * 8) V3D_GNS_LAUNCH(8);
+    else if (nv <= 256 * 16) V3D_GNS_LAUNCH(16);
+    else V3D_GNS_LAUNCH(24);
+#undef V3D_GNS_LAUNCH
+    return v3d_check_launch("v3d_groupnorm_small");
+}
+
 extern "C" int v3d_layernorm(const void* x, const float* add, int64_t add_rpg, int64_t add_ld, void* xsum_out,
                              const float* gamma, const float* beta, void* out, int64_t M, int64_t C, float eps,
                              v3d_stream_t stream) {

@@ -49,9 +49,10 @@ class Env:
 _GN_EPILOGUE = int(os.environ.get("V3D_GN_EPILOGUE", "1") or 0)
 
 
-def _gn_producer(ops, n_stat, rps, cout, device, groups=32, level=1, imgs_per_stat=1):
-    """(stats buffer, GemmCall keywords) for a GEMM whose [M, cout] output feeds a 32-group GroupNorm with `rps` rows per statistics group."""
-    if _GN_EPILOGUE < level or cout % (2 * groups) or rps % 16:
+def _gn_producer(ops, n_stat, rps, cout, device, groups=32, level=1, imgs_per_stat=1, consumer_small=False):
+    """(stats buffer, GemmCall keywords) for a GEMM whose [M, cout] output feeds a 32-group GroupNorm with `rps` rows per statistics group.
+    consumer_small: that GroupNorm will run as ONE launch on its own (ops.groupnorm -> v3d_groupnorm_small: 8 x 8 level) - no sums wanted."""
+    if consumer_small or _GN_EPILOGUE < level or cout % (2 * groups) or rps % 16:
         return None, {}
     st = ops.gn_stats_buffer(n_stat, device, groups, rps=rps, imgs_per_stat=imgs_per_stat)
     return st, dict(gn_stats=st, gn_rps=rps, gn_cpg=cout // groups)
@@ -62,10 +63,26 @@ def _gn_producer(ops, n_stat, rps, cout, device, groups=32, level=1, imgs_per_st
 _CONV_GN = os.environ.get("V3D_CONV_GN", "1") not in ("", "0")
 
 
+def _halo_level(g: "Geo") -> bool:
+    """Levels the LDS-haloed 3x3 kernels exist for (conv.hip: W in {64, 32, 16})."""
+    return _CONV_GN and g.W in (16, 32, 64)
+
+
+def _small_norm(ops, g: "Geo", cout, imgs_per_stat=1) -> bool:
+    """Will the GroupNorm of a [n*S, cout] tensor produced at this level run as one launch (v3d_groupnorm_small)?  2-D norms only below
+    the haloed kernels' levels (there the norm rides the convolution's operand path); the 3-D norm wherever its statistics group fits."""
+    if imgs_per_stat == 1 and _halo_level(g) and cout % 320 == 0:
+        return False
+    return ops._GN_SMALL and ops.groupnorm_small_supported(cout, 0, g.S, imgs_per_stat)
+
+
 def conv3x3_gn(ops, x1, x2, norm, w, bias, g: "Geo", *, stats=None, out=None, **epi):
     """conv3x3(SiLU(GroupNorm(x1 | x2))): openaimodel.py:267-271 (in_layers) / 302-314 (out_layers), 2-D norm (one statistics group per image)."""
     ga, be, eps = norm
     n, S = g.n, g.S
+    if stats is None and not _halo_level(g) and ops.groupnorm_small_fits(x1, x2, S, 1):
+        h = ops.groupnorm(x1, x2, ga, be, n, S, eps=eps, silu=True)          # one launch (8 x 8 level)
+        return ops.conv3x3(h, w, bias, n, g.H, g.W, out=out, **epi)
     table = ops.groupnorm_table(x1, x2, ga, be, n, S, eps=eps, stats=stats)
     N = w.shape[-2]
     K = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
@@ -91,7 +108,7 @@ def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[tor
     if p.emb_off >= 0:
         epi = dict(add=env.emb_all[:, p.emb_off:], add_rpg=S, add_ld=env.emb_all.stride(0))
     cout = p.w1.shape[-2]
-    st2, gkw = _gn_producer(ops, g.n, S, cout, x1.device)
+    st2, gkw = _gn_producer(ops, g.n, S, cout, x1.device, consumer_small=_small_norm(ops, g, cout))
     h = conv3x3_gn(ops, x1, x2, p.gn1, p.w1, p.b1, g, **epi, **gkw)
     if p.skip_w is None:
         assert x2 is None
@@ -105,7 +122,8 @@ def res_spatial(env: Env, g: Geo, p: ResPack, x1: torch.Tensor, x2: Optional[tor
             skip = ops.linear(x2, p.skip_w[:, c1:], None, res1=skip)
     if not out_stats_imgs:
         return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip, out=out)
-    st, gkw = _gn_producer(ops, g.n // out_stats_imgs, out_stats_imgs * S, p.w2.shape[-2], x1.device, imgs_per_stat=out_stats_imgs)
+    st, gkw = _gn_producer(ops, g.n // out_stats_imgs, out_stats_imgs * S, p.w2.shape[-2], x1.device, imgs_per_stat=out_stats_imgs,
+                           consumer_small=env.shard is None and _small_norm(ops, g, p.w2.shape[-2], out_stats_imgs))
     return conv3x3_gn(ops, h, None, p.gn2, p.w2, p.b2, g, stats=st2, res1=skip, out=out, **gkw), st
 
 
@@ -113,8 +131,11 @@ def convt3_gn(ops, x, norm, w, bias, g: "Geo", *, stats=None, **epi):
     """conv_t(SiLU(GroupNorm3d(x))) of the time_stack (video_model.py:42-55): 3-D norm (one statistics group per sample), (3,1,1) convolution."""
     ga, be, eps = norm
     n, S, T = g.n, g.S, g.T
-    table = ops.groupnorm_table(x, None, ga, be, n, S, eps=eps, imgs_per_stat=T, stats=stats)
     N, K = w.shape[-2], x.shape[-1]
+    if stats is None and ops.groupnorm_small_fits(x, None, S, T):
+        h = ops.groupnorm(x, None, ga, be, n, S, eps=eps, silu=True, imgs_per_stat=T)      # one launch (8 x 8 level)
+        return ops.convt3(h, w, bias, T, S, **epi)
+    table = ops.groupnorm_table(x, None, ga, be, n, S, eps=eps, imgs_per_stat=T, stats=stats)
     # Policy (the library answers whether it CAN, this is whether it PAYS): with 3 taps per chunk the temporal kernel has two steps of MFMA
     # slots for its normalisation chain and 192 x 320 tiles only - measured (tools/conv_gn_bench.py, tools/op_times.py) it beats "apply, then
     # the v3 / v2 / split-K kernels" only where those tiles fill the CUs: the 64x64 level (768 tiles, x1.08-1.15); 384 tiles at 32x32 x0.85,
@@ -148,7 +169,8 @@ def res_temporal(env: Env, g: Geo, p: ResPack, xs: torch.Tensor, *, coef=None, c
         epi2.update(coef=coef, coef_rpg=S)
     else:
         epi2.update(c_acc=c_acc, c_res1=1.0)
-    st2, gkw = _gn_producer(ops, g.n // T, T * S, p.t_w1.shape[-2], xs.device, level=2, imgs_per_stat=T)
+    st2, gkw = _gn_producer(ops, g.n // T, T * S, p.t_w1.shape[-2], xs.device, level=2, imgs_per_stat=T,
+                            consumer_small=sh is None and _small_norm(ops, g, p.t_w1.shape[-2], T))
     if sh is None:
         h = convt3_gn(ops, xs, p.t_gn1, p.t_w1, p.t_b1, g, stats=xs_stats, **epi1, **gkw)
         return convt3_gn(ops, h, p.t_gn2, p.t_w2, p.t_b2, g, stats=st2, **epi2)

@@ -60,6 +60,8 @@ SIGNATURES = {
     "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_i64, c_vp]),
     "v3d_groupnorm_finalize": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_f64, c_f32, c_vp, c_vp]),
     "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "v3d_groupnorm_small_supported": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i64]),
+    "v3d_groupnorm_small": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i64, c_f32, c_i32, c_vp]),
     "v3d_layernorm": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp]),
     "v3d_attn_spatial": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "v3d_attn_temporal": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64,
@@ -292,6 +294,22 @@ class HipOps(OpsBase):
         self._check(self.lib.v3d_groupnorm_finalize(_ptr(stats), 0 if stats is None else stats.shape[1], _ptr(sums), n_stat, groups,
                                                     _ptr(gamma) if table is not None else None, _ptr(beta) if table is not None else None, Cc,
                                                     float(count), float(eps), _ptr(table), self._stream()), "v3d_groupnorm_finalize")
+
+    def groupnorm_small_supported(self, C1, C2, S, imgs_per_stat=1, groups=32):
+        return bool(self.lib.v3d_groupnorm_small_supported(C1, C2, S, groups, imgs_per_stat))
+
+    def groupnorm_small(self, x1, x2, gamma, beta, out, n_img, S, *, eps, silu, imgs_per_stat=1, groups=32):
+        bf = torch.bfloat16
+        self._req(x1, bf, "gns.x1"); self._req_c(gamma, torch.float32, "gns.gamma"); self._req_c(beta, torch.float32, "gns.beta"); self._req_c(out, bf, "gns.out")
+        C1, C2 = x1.shape[-1], 0
+        assert x1.stride(-1) == 1 and x1.stride(0) == C1
+        if x2 is not None:
+            self._req(x2, bf, "gns.x2")
+            C2 = x2.shape[-1]
+            assert x2.stride(-1) == 1 and x2.stride(0) == C2
+        self._check(self.lib.v3d_groupnorm_small(x1.data_ptr(), C1, _ptr(x2), C2, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), n_img, S, groups,
+                                                 imgs_per_stat, eps, int(silu), self._stream()), "v3d_groupnorm_small")
+        return out
 
     def groupnorm_apply(self, x1, x2, table, out, n_img, S, imgs_per_stat, silu):
         bf, f32 = torch.bfloat16, torch.float32

@@ -8,6 +8,8 @@ each C-ABI op) through :func:`use_backend` to check the host logic and as the pe
 """
 from __future__ import annotations
 
+import os
+
 import contextlib
 import dataclasses
 from typing import Optional
@@ -208,15 +210,30 @@ class OpsBase:
                   count_imgs=None, out=None, stats=None, table=None):
         """GroupNorm(+SiLU) over channels-last x1 (and optional channel-concatenated x2): statistics -> table -> apply."""
         C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
-        if table is None:
-            table = self.groupnorm_table(x1, x2, gamma, beta, n_img, S, eps=eps, imgs_per_stat=imgs_per_stat, groups=groups,
-                                         stats_hook=stats_hook, count_imgs=count_imgs, stats=stats)
         if out is None:
             out = self.empty((n_img * S, C), self.act_dtype, x1.device)
         if tuple(out.shape) != (n_img * S, C):
             raise ValueError(f"groupnorm: out has shape {tuple(out.shape)}, the normalised tensor is [{n_img * S}, {C}]")
+        if table is None and stats is None and stats_hook is None and self.groupnorm_small_fits(x1, x2, S, imgs_per_stat, groups):
+            # small statistics groups (8 x 8 level, the 16 x 16 level's transformer norms): one launch instead of three launch-bound ones
+            return self.groupnorm_small(x1, x2, gamma, beta, out, n_img, S, eps=eps, silu=silu, imgs_per_stat=imgs_per_stat, groups=groups)
+        if table is None:
+            table = self.groupnorm_table(x1, x2, gamma, beta, n_img, S, eps=eps, imgs_per_stat=imgs_per_stat, groups=groups,
+                                         stats_hook=stats_hook, count_imgs=count_imgs, stats=stats)
         self.groupnorm_apply(x1, x2, table, out, n_img, S, imgs_per_stat, silu)
         return out
+
+    _GN_SMALL = os.environ.get("V3D_GN_SMALL", "1") not in ("", "0")      # A/B knob: 0 = always statistics -> finalize -> apply
+
+    def groupnorm_small_fits(self, x1, x2, S, imgs_per_stat=1, groups=32) -> bool:
+        """Would `groupnorm` take the one-launch form for this tensor (given no statistics from a producer and no cross-rank sums)?  Producers
+        ask before they spend an epilogue / a statistics pass on sums nobody will read."""
+        if not self._GN_SMALL or x1.stride(0) != x1.shape[-1] or (x2 is not None and x2.stride(0) != x2.shape[-1]):
+            return False
+        return self.groupnorm_small_supported(x1.shape[-1], 0 if x2 is None else x2.shape[-1], S, imgs_per_stat, groups)
+
+    def groupnorm_small_supported(self, C1, C2, S, imgs_per_stat=1, groups=32) -> bool:
+        return False
 
     def gemm_gn_in_supported(self, g: "GemmCall") -> bool:
         """Backends that can normalise a GEMM operand in flight answer per call (HipOps asks the library)."""
