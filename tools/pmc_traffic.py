@@ -34,7 +34,7 @@ def per_kernel(path, counter):
 
 def family(name):
     for key, fam in (("ff_fused_kernel", "gemm_ff_fused"), ("conv_halo_kernel", "gemm_conv_halo"), ("ln_proj_kernel", "gemm_ln_proj"), ("gemm_kernel_v3", "gemm_v3"), ("gemm_kernel_v2", "gemm_v2"), ("gemm_kernel_v1", "gemm_v1"), ("attn_spatial", "attn_spatial"),
-                     ("attn_temporal", "attn_temporal"), ("gn_stats", "gn_stats"), ("gn_finalize", "gn_finalize"), ("gn_apply", "gn_apply"), ("layernorm", "layernorm"),
+                     ("attn_temporal", "attn_temporal"), ("gn_stats", "gn_stats"), ("gn_finalize", "gn_finalize"), ("gn_apply", "gn_apply"), ("gn_small", "gn_small"), ("layernorm", "layernorm"),
                      ("copy2d", "copy2d(calibration)")):
         if key in name:
             return fam
