@@ -31,6 +31,11 @@ class VideoResBlock(ResnetBlock):
         else:
             raise ValueError(f"unknown merge strategy {merge_strategy}")
 
+    def forward(self, x, temb=None, skip_video=False, timesteps=None):
+        """The block on its own (temporal_ae.py:59-82): x [(b t), C, H, W] -> [(b t), out_channels, H, W], timesteps = frames per sample."""
+        from ....engine.standalone import vae_video_resblock
+        return vae_video_resblock(self, x, temb, skip_video, timesteps)
+
 
 class AE3DConv(nn.Conv2d):
     """Conv2d followed by a (3,1,1) Conv3d over frames on the output channels (temporal_ae.py:86-107)."""

@@ -65,6 +65,11 @@ class AttnBlock(_EngineOnly):
         self.v = nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
         self.proj_out = nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
 
+    def forward(self, x, **kwargs):
+        """The block on its own (model.py:180-201): x [n, C, H, W] -> x + proj_out(attention(norm(x)))."""
+        from ....engine.standalone import vae_attn_block
+        return vae_attn_block(self, x)
+
 
 MemoryEfficientAttnBlock = AttnBlock  # same maths (model.py:204-274)
 

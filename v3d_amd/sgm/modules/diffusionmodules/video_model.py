@@ -32,6 +32,12 @@ class VideoResBlock(ResBlock):
                                    use_checkpoint=use_checkpoint, exchange_temb_dims=True)
         self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy, rearrange_pattern="b t -> b 1 t 1 1")
 
+    def forward(self, x: torch.Tensor, emb: torch.Tensor, num_video_frames: int, image_only_indicator: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The block on its own (video_model.py:68-101): x [(b t), C, H, W], emb [(b t), emb_channels] -> [(b t), out_channels, H, W].
+        Inside VideoUNet the same executors run with every block's embedding projected in one GEMM (v3d_amd.engine.unet)."""
+        from ....engine.standalone import unet_video_resblock
+        return unet_video_resblock(self, x, emb, num_video_frames, image_only_indicator)
+
 
 class VideoUNet(nn.Module):
     def __init__(self, in_channels: int, model_channels: int, out_channels: int, num_res_blocks: int,

@@ -69,3 +69,10 @@ class SpatialVideoTransformer(SpatialTransformer):
         self.time_pos_embed = nn.Sequential(nn.Linear(self.in_channels, time_embed_dim), nn.SiLU(),
                                             nn.Linear(time_embed_dim, self.in_channels))
         self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy)
+
+    def forward(self, x, context=None, time_context=None, timesteps=None, image_only_indicator=None):
+        """The block on its own (video_attention.py:230-301): x [(b t), C, H, W], context [(b t), 1, context_dim] -> [(b t), C, H, W].
+        use_spatial_context: time_context = context[::timesteps].  Inside VideoUNet the same executor runs (v3d_amd.engine.unet.run_svt)."""
+        from ...engine.standalone import spatial_video_transformer
+        assert self.use_spatial_context, "only use_spatial_context=True (V3D / SVD) is implemented"
+        return spatial_video_transformer(self, x, context, time_context, timesteps, image_only_indicator)
