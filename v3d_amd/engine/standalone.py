@@ -128,3 +128,74 @@ def vae_attn_block(ab, x):
     ops.begin_evaluation(x.device)
     out = run_vae_attn(Env(ops=ops), Geo(n=n, B=n, T=1, H=H, W=W), p, _rows(ops, x))
     return _nchw(out, n, H, W, x)
+
+
+# ---- the smaller owners of the spatial transformer, as plain op sequences (inside the networks their arithmetic is fused across module
+#      boundaries - LayerNorm into projections, the feed-forward in one kernel, the 1-token cross-attention folded into a vector) ------------
+def _tokens(ops, x):
+    """[..., C] -> bf16 rows [M, C] (zero-copy when x already is a contiguous bf16 row matrix)."""
+    from .unet import _cast_rows_bf16
+    return _cast_rows_bf16(ops, x.reshape(-1, x.shape[-1]))
+
+
+def feed_forward_module(ff, x):
+    """FeedForward.forward (attention.py:82-113): Linear(value | gate) -> value * gelu(gate) -> Linear, any leading dims."""
+    from .packing import _pack_ff
+    ops = get_ops()
+    p = _cached(ff, lambda: _pack_ff(ff))
+    rows = _tokens(ops, x)
+    h = ops.linear(rows, p.w1, p.b1, geglu=True)
+    return ops.linear(h, p.w2, p.b2).view(*x.shape[:-1], -1).to(x.dtype)
+
+
+def cross_attention_module(at, x, context=None, mask=None):
+    """CrossAttention.forward (attention.py:286-349) for the two cases V3D / SVD use: self-attention over x [B, N, C] (heads of 64), and
+    cross-attention to ONE context token per batch element (softmax over a single key is 1: out = to_out(to_v(context)), exact)."""
+    from ..ops import GemmCall
+    from .packing import pack_linear
+    assert mask is None, "attention masks are not used by V3D / SVD"
+    ops = get_ops()
+    B, N, C = x.shape
+    dev = x.device
+
+    def build():
+        wq, wk, wv = (_bf(m.weight) for m in (at.to_q, at.to_k, at.to_v))
+        return wq, wk, wv, pack_linear(at.to_out[0])
+
+    wq, wk, wv, wo = _cached(at, build)
+    inner = wq.shape[0]
+    if context is not None:
+        if context.dim() != 3 or context.shape[0] != B or context.shape[1] != 1:
+            raise NotImplementedError("CrossAttention with more than one context token per batch element is not used by V3D / SVD")
+        v = ops.linear(_tokens(ops, context), wv)                                   # [B, inner]
+        o = ops.linear(v, wo[0], wo[1], out_dtype=F32)                              # [B, C]
+        return o[:, None, :].expand(B, N, o.shape[-1]).to(x.dtype).contiguous()
+    assert at.dim_head == 64, "attention kernels are specialised for dim_head = 64"
+    rows = _tokens(ops, x)
+    q, k = ops.linear(rows, wq), ops.linear(rows, wk)
+    vT = ops.empty((B, inner, N), ops.act_dtype, dev)
+    ops.gemm(GemmCall(A=wv, W=rows.view(B, N, C), out=vT, M=inner, N=N, K=C, batch=B))
+    a = ops.empty((B * N, inner), ops.act_dtype, dev)
+    ops.attn_spatial(q, k, vT, a, B, N, at.heads, float(at.scale))
+    return ops.linear(a, wo[0], wo[1]).view(B, N, -1).to(x.dtype)
+
+
+def basic_transformer_block(blk, x, context=None):
+    """BasicTransformerBlock._forward (attention.py:556-577): x + attn1(norm1 x); + attn2(norm2 x, context); + ff(norm3 x).  x [B, N, C]."""
+    from .packing import pack_norm
+    ops = get_ops()
+    B, N, C = x.shape
+    cur = _tokens(ops, x)
+
+    def ln(norm, rows):
+        ga, be, eps = pack_norm(norm)
+        out = ops.empty(tuple(rows.shape), ops.act_dtype, rows.device)
+        ops.layernorm(rows, ga, be, out, eps)
+        return out
+
+    cur = (cross_attention_module(blk.attn1, ln(blk.norm1, cur).view(B, N, C)).reshape(B * N, C).float() + cur.float())
+    cur = _tokens(ops, cur)
+    cur = (cross_attention_module(blk.attn2, ln(blk.norm2, cur).view(B, N, C), context).reshape(B * N, C).float() + cur.float())
+    cur = _tokens(ops, cur)
+    cur = feed_forward_module(blk.ff, ln(blk.norm3, cur)).float() + cur.float()
+    return cur.view(B, N, C).to(x.dtype)

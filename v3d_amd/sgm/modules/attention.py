@@ -49,6 +49,11 @@ class FeedForward(_EngineOnly):
         dim_out = default(dim_out, dim)
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
 
+    def forward(self, x):
+        """The module on its own (attention.py:82-113); inside the networks it runs fused with its LayerNorm and residual (v3d_ff_fused)."""
+        from ...engine.standalone import feed_forward_module
+        return feed_forward_module(self, x)
+
 
 class CrossAttention(_EngineOnly):
     """to_q/to_k/to_v (no bias) + to_out.0 (bias).  Registered under both reference mode keys below."""
@@ -64,6 +69,11 @@ class CrossAttention(_EngineOnly):
         self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+
+    def forward(self, x, context=None, mask=None, **kwargs):
+        """The module on its own (attention.py:286-349): self-attention over x [B, N, C], or cross-attention to ONE context token."""
+        from ...engine.standalone import cross_attention_module
+        return cross_attention_module(self, x, context, mask)
 
 
 MemoryEfficientCrossAttention = CrossAttention  # same maths; the HIP flash kernel serves both mode strings
@@ -87,6 +97,11 @@ class BasicTransformerBlock(_EngineOnly):
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
         self.checkpoint = checkpoint
+
+    def forward(self, x, context=None, **kwargs):
+        """The block on its own (attention.py:556-577), x [B, N, C]; inside the networks it is part of run_svt's fused sequence."""
+        from ...engine.standalone import basic_transformer_block
+        return basic_transformer_block(self, x, context)
 
 
 class SpatialTransformer(_EngineOnly):
