@@ -18,6 +18,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         extra = ["-fno-slp-vectorize"] if src.endswith("ff.hip") else []
+        extra += os.environ.get("EXTRA_FLAGS", "").split()       # e.g. EXTRA_FLAGS="-DE4_DEPTH=2": audit an A/B build
         subprocess.run(["hipcc", *FLAGS, *extra, "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     parts = re.split(r"\n(_Z[^\n:]+):[^\n]*\n", text)

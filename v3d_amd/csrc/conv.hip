@@ -30,6 +30,13 @@
 #define CONV_ABL 0
 #endif
 #define CABL(bit) ((CONV_ABL & (bit)) != 0)
+// Main-loop placement A/B (compile-time, tools/mainloop_ab.sh): bit 1 = the weight pieces of a step are issued from INSIDE its MFMA sequence
+// (one piece behind MFMA 6 / 15 / 24) instead of behind the fragment reads: the read phase of a wave - which the partner group's MFMA
+// phase has to cover - loses the ~250 cycles its waves spend queueing on the texture-address unit.  bit 2 = no s_setprio around the MFMAs.
+#ifndef CONV_MLV
+#define CONV_MLV 0
+#endif
+#define CMLV(bit) ((CONV_MLV & (bit)) != 0)
 
 namespace {
 
@@ -46,7 +53,7 @@ struct HaloGeom {
     static constexpr int HBYTES = HPW * 8 * 1024;
     static constexpr int NBUF = HM == HM_CONV ? 2 : 3;                                // halo images in flight
     static constexpr int LA = NBUF - 1;                                               // chunks of look-ahead of the halo loader
-    static constexpr int XF0 = 3;                                                     // first step (after the issue step) whose MFMA slots carry the transform
+    static constexpr int XF0 = (CMLV(4) && HM == HM_CONV) ? 4 : 3;                                                     // first step (after the issue step) whose MFMA slots carry the transform
     static constexpr int XFN = LA * NT - 4;                                           // ... and how many steps do
     static constexpr int NTAB = XF0 >= NT ? 2 : 1;                                    // (scale, shift) slots per wave: 2 when a chunk's chain runs beside the next issue
     static_assert(XFN >= 1, "halo pipeline too shallow");
@@ -172,16 +179,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         w_c = q.u0;
         w_c1 = q.u1;
     };
-    auto issue_w = [&](int stage, int ltap) __attribute__((always_inline)) {
+    auto issue_w_piece = [&](int stage, int ltap, int i) __attribute__((always_inline)) {
         if (CABL(4)) return;
+        // scalar offset: tap, chunk and the piece's 16-row block (N % 320 == 0: every row of the tile exists)
+        const int so = (int)(ltap * tap_bytes) + w_c * 64 + (w_n0 / 16 + wave + NW * i) * row16_bytes;
+        if (i < 2 || grp == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + RING_OFF + stage * WSTAGE + (wave + NW * i) * 1024), 16,
+                                                     (int)voffW, so, 0, 0);
+    };
+    auto issue_w = [&](int stage, int ltap) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            // scalar offset: tap, chunk and the piece's 16-row block (N % 320 == 0: every row of the tile exists)
-            const int so = (int)(ltap * tap_bytes) + w_c * 64 + (w_n0 / 16 + wave + NW * i) * row16_bytes;
-            if (i < 2 || grp == 0)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + RING_OFF + stage * WSTAGE + (wave + NW * i) * 1024), 16,
-                                                         (int)voffW, so, 0, 0);
-        }
+        for (int i = 0; i < 3; ++i) issue_w_piece(stage, ltap, i);
     };
     // ---------------------------------------------------------------- halo loader (LA chunks ahead)
     const bufrsrc_t rsA1 = make_rsrc(p.A, p.a_bytes);
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         for (int i = 0; i < HPW; ++i) {
             bool second_stat;
             const unsigned row = halo_row(ht, i, second_stat, ln);
-            const unsigned vo = row == kInvalid ? kInvalid : row * ld2 + (unsigned)hchunkpos * 16u;
+            const unsigned vo = row == kInvalid ? kInvalid : (CABL(65536) ? (row & 1023u) : row) * ld2 + (unsigned)hchunkpos * 16u;     // (65536: L2-hot source rows)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rsA2 : rsA1, (__attribute__((address_space(3))) void*)(lds + HALO_OFF + h_buf * HBYTES + (wave + NW * i) * 1024), 16,
                                                      (int)vo, cc * 64, 0, 0);
         }
@@ -445,6 +453,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 constexpr int tap = decltype(tap_)::value;
                 constexpr int dy = HM == HM_CONV ? tap / 3 : tap, dx = HM == HM_CONV ? tap % 3 : 0;
                 constexpr int ltap = (tap + NS - 1) % NT;             // the weight loader's tap, NS-1 steps ahead
+                // (bit 8: the odd waves of a group put their weight pieces IN FRONT of their fragment reads, the even ones behind: two waves queue
+                // on the TA while two read the LDS, then they swap - four waves doing the same thing at once wait ~66 cycles per DMA piece)
+                const int wst_early = rd == 0 ? NS - 1 : rd - 1;
+                const bool early = CMLV(8) && tap != 0 && (wave & 1);
+                if (CMLV(8) && tap != 0) {
+                    if constexpr (ltap == 0) {
+                        if (++w_c == w_c1) set_wtile(++w_it);
+                    }
+                    if (early) issue_w(wst_early, ltap);
+                }
                 // ---- fragment reads of this step
                 if (!CABL(4096)) {
                     const unsigned char* sb = lds + RING_OFF + rd * WSTAGE + wfrag_off;
@@ -466,29 +484,38 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 }
                 // ---- loaders: the halo image LA chunks ahead (first step of a chunk), then the weights 3 steps ahead
                 if constexpr (tap == G::XF0 % NT) xf_begin();     // (ahead of this step's issue: with NT <= XF0 the chain belongs to the PREVIOUS issue)
-                if constexpr (tap == 0) issue_halo();
+                if constexpr (tap == 0 && !(CMLV(4) && HM == HM_CONV)) issue_halo();
                 if constexpr (ltap == 0) {                            // the weight cursor enters the next chunk
-                    if (++w_c == w_c1) set_wtile(++w_it);
+                    if (!(CMLV(8) && tap != 0)) {
+                        if (++w_c == w_c1) set_wtile(++w_it);
+                    }
                 }
-                issue_w(rd == 0 ? NS - 1 : rd - 1, ltap);
+                const int wst = rd == 0 ? NS - 1 : rd - 1;
+                if (!CMLV(1) && !early) issue_w(wst, ltap);
+                if constexpr (tap == 0 && CMLV(4) && HM == HM_CONV) issue_halo();      // (bit 4: BEHIND this step's weights - the in-order vmcnt then asks for the halo one step later)
                 rd = (rd + 1 == NS) ? 0 : rd + 1;
                 // DMA ops younger than the pieces of the NEXT step's weight stage (issued two steps ago): two weight stages, plus the halo
                 // pieces + table piece when one of the last two issue points was a chunk's first step (they are issued AHEAD of that step's weights)
-                constexpr int HL = (tap == 0 || tap == 1) ? HPW + (XF ? 1 : 0) : 0;
+                constexpr int HL = (tap == 0 || tap == 1 || (CMLV(4) && HM == HM_CONV && tap == 2)) ? HPW + (XF ? 1 : 0) : 0;
                 if (grp == 1 && !CABL(32768)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 + HL) : "memory");
+                    // (weights issued inside the MFMA sequence: this step's pieces are not out yet - one younger stage instead of two)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((CMLV(1) ? 2 : 2 * 2) + HL) : "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_s_setprio(1);
+                if (!CMLV(2)) __builtin_amdgcn_s_setprio(1);
                 // ---- 30 MFMAs, one instruction of the normalisation chain per issue slot
                 constexpr int XSTEP = ((tap - G::XF0) % NT + NT) % NT;    // (3x3: taps 3..7 carry the chain of the image issued at tap 0)
                 constexpr int NOPS = HPW * 4 * 15, NSLOT = G::XFN * 30;
                 static_for<0, MF * NF>([&](auto n_) {
                     constexpr int n = decltype(n_)::value, i = n / NF, j = n % NF;
                     if (!CABL(2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                    if constexpr (CMLV(1) && (n == 6 || n == 15 || n == 24)) {
+                        issue_w_piece(wst, ltap, (n - 6) / 9);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if constexpr (XF && XSTEP >= 0 && XSTEP < G::XFN && !CABL(16384)) {
                         constexpr int s0 = XSTEP * 30 + n;
                         constexpr int o0 = (s0 * NOPS) / NSLOT, o1 = ((s0 + 1) * NOPS) / NSLOT;
@@ -496,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
-                __builtin_amdgcn_s_setprio(0);
+                if (!CMLV(2)) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (grp == 0 && !CABL(32768)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (its in-place ds_writes are inline asm)
@@ -545,17 +572,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             }
             // hand-managed epilogue (gemm_common.h e4_*): asm loads one fragment ahead, one wait per fragment
             auto rowfn = [&](int f) __attribute__((always_inline)) -> long long { return frag_row0<HM>(q, f); };
-            auto flushfn = [&](int f, long long m0f, unsigned& slot) __attribute__((always_inline)) -> bool {
-                // writer = this wave tile's run of rows inside one statistics group; its slot is unique inside the group (gn_flush)
-                bool flush = f + 1 == MF;
+            // (3x3: consecutive 16-row fragments, E4GnRun; temporal: the wave's 3 frames x 32 positions lie in one statistics group - the sample)
+            E4GnRun<WM, MF> run;
+            unsigned tsid = 0;
+            if constexpr (GN) {
+                if (HM == HM_CONV) run.init(q.mw0, p.gn_rps);
+                else tsid = e4_udiv((unsigned)q.mw0, (unsigned)p.gn_rps);
+            }
+            auto flushfn = [&](int f, long long, unsigned& slot, unsigned& sid) __attribute__((always_inline)) -> bool {
+                if (HM == HM_CONV) return run.step(f, slot, sid);
                 slot = q.tslot;
-                if (HM == HM_CONV) {
-                    const long long sid = m0f / p.gn_rps;
-                    flush = flush || (m0f + 16) / p.gn_rps != sid;
-                    const long long first = q.mw0 / p.gn_rps == sid ? q.mw0 - sid * p.gn_rps : 0;
-                    slot = (unsigned)((first + WM - 1) / WM);
-                }
-                return flush;
+                sid = tsid;
+                return f + 1 == MF;
             };
             // (an opaque copy of the lane id: everything the epilogue derives from it is computed here, per tile - as loop invariants those values
             // were hoisted in front of the main loop, spilled there, and re-read from scratch ~20 times per fragment)

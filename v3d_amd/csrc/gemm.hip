@@ -34,6 +34,15 @@
 #ifndef V3D_GEMM_TAPINNER_DEFAULT
 #define V3D_GEMM_TAPINNER_DEFAULT 0
 #endif
+// Main-loop placement A/B of the v3 kernels (compile-time, tools/mainloop_ab.sh): bit 1 = the LDS-DMA pieces of a step are issued from INSIDE its
+// MFMA sequence (evenly spaced) instead of behind the fragment reads (see conv.hip CONV_MLV).
+#ifndef GEMM_MLV
+#define GEMM_MLV 0
+#endif
+#ifndef V3D_GEMM_V4_DEFAULT
+#define V3D_GEMM_V4_DEFAULT 0
+#endif
+#define GMLV(bit) ((GEMM_MLV & (bit)) != 0)
 
 namespace {
 
@@ -476,6 +485,12 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     for (int it = 0; it < my_tiles; ++it) {
         for (int kt = 0; kt < nsteps; ++kt, ++s) {
             stamp(s, 0);
+            const bool early = GMLV(8) && (wave & 1);         // (bit 8: odd waves issue their DMA pieces in front of their fragment reads, see conv.hip)
+            if (early) {
+                const int so = __builtin_amdgcn_readfirstlane(ld_k0 * 2);
+#pragma unroll
+                for (int i = 0; i < PPW; ++i) issue_piece(rd == 0 ? NS - 1 : rd - 1, i, so);
+            }
             {
                 const unsigned char* sb = lds + rd * STAGE_BYTES;
 #pragma unroll
@@ -485,7 +500,11 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
             }
             // refill the ring 3 stages ahead (the buffer of step s-1: its last reader, group 1, finished before B_s) while the
             // fragment reads are in flight
-            issue(rd == 0 ? NS - 1 : rd - 1);
+            const int wst = rd == 0 ? NS - 1 : rd - 1;
+            if (!GMLV(1)) {
+                if (early) issue_advance();
+                else issue(wst);
+            }
             rd = (rd + 1 == NS) ? 0 : rd + 1;
             stamp(s, 1);
             // group 1 must have its fragments in registers before it passes the barrier (the slot is refilled after it);
@@ -496,20 +515,39 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
             }
             stamp(s, 2);
             if (grp == 1) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");   // own pieces of stage s+1 landed
+                // own pieces of stage s+1 landed (pieces issued inside the MFMA sequence: this step's are not out yet - one younger stage fewer)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (GMLV(1) ? NS - 3 : NS - 2)) : "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
             stamp(s, 3);
-            if (!V3D_ABL(p, 256)) __builtin_amdgcn_s_setprio(1);
+            if (!V3D_ABL(p, 256) && !GMLV(2)) __builtin_amdgcn_s_setprio(1);
             if (!V3D_ABL(p, 2)) {
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
+                if constexpr (GMLV(1)) {
+                    const int so = __builtin_amdgcn_readfirstlane(ld_k0 * 2);
+                    static_for<0, MF * NF>([&](auto n_) {
+                        constexpr int n = decltype(n_)::value, i = n / NF, j = n % NF;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                        // piece k behind MFMA (k + 1) * 30 / (PPW + 1) - 1
+                        static_for<0, PPW>([&](auto k_) {
+                            constexpr int k = decltype(k_)::value;
+                            if constexpr (n == (k + 1) * (MF * NF) / (PPW + 1) - 1) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(wst, k, so);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                    });
+                    issue_advance();
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                }
             }
-            if (!V3D_ABL(p, 256)) __builtin_amdgcn_s_setprio(0);
+            if (!V3D_ABL(p, 256) && !GMLV(2)) __builtin_amdgcn_s_setprio(0);
             stamp(s, 4);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) {
@@ -530,13 +568,9 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));          // (keeps what the epilogue derives from the lane id out of the loop-invariant set: no spills)
                 auto rowfn = [&](int f) __attribute__((always_inline)) -> long long { return mw0 + f * 16; };
-                auto flushfn = [&](int f, long long m0f, unsigned& slot) __attribute__((always_inline)) -> bool {
-                    // writer = this wave tile's run of rows inside one statistics group; its slot is unique inside the group (gn_flush)
-                    const long long sid = m0f / p.gn_rps;
-                    const long long first = mw0 / p.gn_rps == sid ? mw0 - sid * p.gn_rps : 0;
-                    slot = (unsigned)((first + WM - 1) / WM);
-                    return f + 1 == MF || (m0f + 16) / p.gn_rps != sid;
-                };
+                E4GnRun<WM, MF> run;
+                if constexpr (GN) run.init(mw0, p.gn_rps);
+                auto flushfn = [&](int f, long long, unsigned& slot, unsigned& sid) __attribute__((always_inline)) -> bool { return run.step(f, slot, sid); };
                 e4_retire_tile<MF, NF, GN>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
             }
         } else
@@ -893,7 +927,25 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
         const bool want = impl_choice() == 3 || fill3 >= fill_k * fill2;
         // (non-GEGLU v3 kernels only carry the hand-managed epilogue: its operand contract on top of the tile-shape one)
         const bool eok = GEGLU || (variant ? e4_ok(p, 96, 80) : e4_ok(p, 128, 64));
-        if (want && eok && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) return launch_v3<MODE, GEGLU>(p, st, variant);
+        if (want && eok && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) {
+            if constexpr (!GEGLU) {
+                // one wave per SIMD, software-pipelined in the wave (gemm4.hip): V3D_GEMM_V4 = 0 never, 1 = every launch it can take
+                static int v4 = -1;
+                if (v4 < 0) {
+                    const char* e = getenv("V3D_GEMM_V4");
+                    v4 = e ? atoi(e) : V3D_GEMM_V4_DEFAULT;
+                }
+                const int v4v = v4 ? v3d_gemm_v4_variant(p, MODE, variant) : 0;
+                if (v4v) {
+                    if (p.gn_stats) {
+                        g_gn_in_epilogue = true;
+                        ++g_gn_epilogue_launches;
+                    }
+                    return v3d_gemm_v4_launch(p, MODE, v4v, (void*)st);
+                }
+            }
+            return launch_v3<MODE, GEGLU>(p, st, variant);
+        }
     }
     if ((cfg_choice() == 5 || cfg_choice() == 6) && impl_choice() != 1 && p.N % 256 == 0 && p.K % 64 == 0 && p.K * 2 <= 65536) return launch256<MODE, GEGLU>(p, batch, st, cfg_choice());
     // N tile: 128 unless a 64-wide tile wastes less (e.g. N = 320: 5 x 64 exact vs 3 x 128 = 17 % padding)

@@ -65,6 +65,9 @@ struct V3dGemmParams {
 // conv.hip: the LDS-haloed kernels (GroupNorm + SiLU in the operand path)
 int v3d_conv_halo_variant(const V3dGemmParams& p, int mode);          // 0 = not one of their shapes
 int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream);
+// gemm4.hip: the one-wave-per-SIMD persistent kernels (0 = not one of their launches, else the variant: 1 = 192 x 320 tiles, 2 = 256 x 256)
+int v3d_gemm_v4_variant(const V3dGemmParams& p, int mode, int v3_variant);
+int v3d_gemm_v4_launch(const V3dGemmParams& p, int mode, int variant, void* stream);
 // gemm.hip: stream-K plan of a persistent launch (fills p.sk_*, returns the grid): ntiles tiles of `units` split granules on the device's CUs;
 // slot_bytes = one block's accumulators in fp32.  Leaves the classic assignment (sk_tail = 0) when the tail round is full enough or too thin.
 int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, int min_saved, size_t slot_bytes, void* stream);
@@ -550,8 +553,14 @@ template <int NF>
 struct E4Tile {
     f32x4 ba[NF];          // bias + per-row-group vector of the lane's 4 channels per fragment column
     float ca, c1, c2;
-    long long add_grp, coef_grp;
+    // row group of the fragment the constants belong to, and the fragment's first row inside it.  Round 3 compared m0f / add_rpg (and coef_rpg,
+    // gn_rps) against these per FRAGMENT: five or six 64-bit software divisions, ~250 of the ~500 instructions a fragment's epilogue
+    // executed.  Now one 32-bit division per divisor and tile; fragments advance the remainders (rows of a launch fit 32 bits: host contract).
+    unsigned add_grp, coef_grp, add_rem, coef_rem;
 };
+__device__ __forceinline__ unsigned e4_udiv(unsigned a, unsigned b) {       // wave-uniform operands: one v_rcp-based 32-bit division, result back in an SGPR
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(a / b));
+}
 __device__ __forceinline__ u32x4 e4_load16(const void* ptr) {
     u32x4 r;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
@@ -577,6 +586,14 @@ __device__ __forceinline__ void e4_load_res(const GP& p, long long m0f, long lon
 __device__ __forceinline__ void e4_wait_res(E4Res& r) {          // everything outstanding has landed; names the destinations (asm loads: form (ii))
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.a2)::"memory");
 }
+// the pieces of `r` have landed once at most N younger VMEM operations of this wave are outstanding (VMEM retires in issue order); the
+// statement names the destinations like e4_wait_res.  N is a LOWER bound of the operations issued behind the loads (an operation the
+// count does not know about - a GroupNorm-statistics store, a reloaded constant - only makes the wait stricter).
+template <int N>
+__device__ __forceinline__ void e4_wait_cnt(E4Res& r) {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.a2) : "n"(N) : "memory");
+}
 // per-row-group constants of the wave tile's fragment starting at row m0f (synchronous: once per tile, and when a fragment enters another group)
 template <int NF>
 __device__ __forceinline__ void e4_tile_consts(const GP& p, long long m0f, long long nw0, int lane, E4Tile<NF>& t) {
@@ -589,15 +606,17 @@ __device__ __forceinline__ void e4_tile_consts(const GP& p, long long m0f, long 
 #pragma unroll
         for (int j = 0; j < NF; ++j) bv[j] = __builtin_bit_cast(f32x4, e4_load16(p.bias + nb + j * 16));
     }
-    t.add_grp = p.add ? m0f / p.add_rpg : 0;
+    t.add_grp = p.add ? e4_udiv((unsigned)m0f, (unsigned)p.add_rpg) : 0u;
+    t.add_rem = p.add ? (unsigned)m0f - t.add_grp * (unsigned)p.add_rpg : 0u;
     if (p.add) {
-        const float* av0 = p.add + t.add_grp * p.add_ld + nb;
+        const float* av0 = p.add + (long long)t.add_grp * p.add_ld + nb;
 #pragma unroll
         for (int j = 0; j < NF; ++j) av[j] = __builtin_bit_cast(f32x4, e4_load16(av0 + j * 16));
     }
-    t.coef_grp = p.coef ? m0f / p.coef_rpg : 0;
+    t.coef_grp = p.coef ? e4_udiv((unsigned)m0f, (unsigned)p.coef_rpg) : 0u;
+    t.coef_rem = p.coef ? (unsigned)m0f - t.coef_grp * (unsigned)p.coef_rpg : 0u;
     if (p.coef) {
-        const float* cf = p.coef + t.coef_grp * 3;
+        const float* cf = p.coef + (long long)t.coef_grp * 3;
         cf0 = e4_load4(cf);
         cf1 = e4_load4(cf + 1);
         cf2 = e4_load4(cf + 2);
@@ -623,12 +642,14 @@ __device__ __forceinline__ void e4_lds_write8(unsigned addr, uint32_t w0, uint32
 }
 
 // one 16-row fragment: acc (+ constants, residuals) -> bf16 -> staged rows -> 16-byte-per-lane row stores.  `cur` = this fragment's residual
-// pieces (landed), `nxt` = the next fragment's (in flight; waited for inside, before this fragment's stores).  Residual #1 goes through the
-// staging rows IN PLACE: its row pieces are written where the output rows will stand, every lane reads its own 8 bytes per fragment
-// column, adds, and writes the bf16 result back to the same 8 bytes (4 live floats per column instead of the whole fragment).
+// pieces (landed: the caller has waited for them).  Residual #1 goes through the staging rows IN PLACE: its row pieces are written where the
+// output rows will stand, every lane reads its own 8 bytes per fragment column, adds, and writes the bf16 result back to the same 8 bytes
+// (4 live floats per column instead of the whole fragment).  NOTHING here waits for a store: the rows leave as plain 16-byte stores that
+// drain while the next fragments are computed (round 3 waited vmcnt(0) once per fragment: the previous fragment's stores and the next
+// fragment's residual loads - 6 serialised memory round trips per wave tile with every CU of the chip in the same phase).
 template <int NF, bool GN>
 __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long long m0f, long long nw0, int lane, unsigned char* stage, const E4Res& cur,
-                                            E4Res& nxt, const E4Tile<NF>& t, GnAcc<GN ? NF : 1>& gn) {
+                                            const E4Tile<NF>& t, GnAcc<GN ? NF : 1>& gn) {
     constexpr int CPRO = NF * 2, NP = 16 * CPRO, SROW = NF * 32 + 16;
     const int fr = lane & 15, fq = (lane >> 4) * 4;
     const unsigned sbase = lds_addr(stage);
@@ -646,7 +667,8 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
             if (NP % 64 == 0 || lane < NP - 128) e4_lds_write16(piece_addr(2), cur.a2);
         }
     }
-    // residual #2 (rare): the lane's 8 bytes per fragment column straight from memory (MFMA layout), fetched and waited for here
+    // residual #2 (rare): the lane's 8 bytes per fragment column straight from memory (MFMA layout), fetched and waited for here (the
+    // vmcnt(0) also lands whatever else the wave has in flight: stricter than the counted waits of e4_retire need, never weaker)
     u32x2 q2[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) q2[j] = u32x2{0u, 0u};
@@ -656,9 +678,9 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
         for (int j = 0; j < NF; ++j) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(q2[j]) : "v"(r2 + j * 16) : "memory");
         static_assert(NF == 4 || NF == 5, "e4: 64- or 80-channel wave tiles");
         if constexpr (NF == 5)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]), "+v"(q2[4]), "+v"(nxt.a0), "+v"(nxt.a1), "+v"(nxt.a2)::"memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]), "+v"(q2[4])::"memory");
         else
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]), "+v"(nxt.a0), "+v"(nxt.a1), "+v"(nxt.a2)::"memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3])::"memory");
     }
     if (has1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -680,8 +702,6 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
             gn_add_pair(gn.s[j][1], gn.q[j][1], w1);
         }
     }
-    // the one wait of the fragment: the previous fragment's stores and the next fragment's residual loads
-    e4_wait_res(nxt);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bf16_t* outz = reinterpret_cast<bf16_t*>(p.out) + m0f * p.ldo + nw0;
 #pragma unroll
@@ -692,40 +712,121 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
     }
 }
 
-// retire the MF fragments of a finished wave tile; RowFn(f) = first output row of fragment f, FlushFn(f, m0f) = (flush?, slot) of the
-// GroupNorm-statistics epilogue.  Residual pieces travel by value (a reference went through a stack array, see conv.hip halo_retire).
-template <int F, int MF, int NF, bool GN, typename RowFn, typename FlushFn>
-__device__ __forceinline__ void e4_retire(const GP& p, f32x4 (&acc)[MF][NF], long long nw0, int lane, unsigned char* stage, E4Res cur, E4Tile<NF> t,
-                                          GnAcc<GN ? NF : 1>& gn, RowFn rowfn, FlushFn flushfn) {
-    if constexpr (F < MF) {
-        const long long m0f = rowfn(F);
-        E4Res nxt = cur;
-        if constexpr (F + 1 < MF) {
-            if (p.res1) e4_load_res<NF>(p, rowfn(F + 1), nw0, lane, nxt);
-        }
-        if ((p.add && m0f / p.add_rpg != t.add_grp) || (p.coef && m0f / p.coef_rpg != t.coef_grp)) {
-            e4_wait_res(nxt);                 // (rare: the wave tile straddles two row groups - the constants' wait below must not strand these)
-            e4_tile_consts<NF>(p, m0f, nw0, lane, t);
-        }
-        e4_fragment<NF, GN>(p, acc[F], m0f, nw0, lane, stage, cur, nxt, t, gn);
-        if constexpr (GN) {
-            unsigned slot = 0;
-            if (flushfn(F, m0f, slot)) gn_flush<NF>(p, gn, m0f / p.gn_rps, nw0, lane, stage, slot);
-        }
-        e4_retire<F + 1, MF, NF, GN>(p, acc, nw0, lane, stage, nxt, t, gn, rowfn, flushfn);
+// Residual pieces run E4_DEPTH fragments ahead of their use (round 3: one fragment, waited for together with the previous fragment's stores).
+// A fragment's arithmetic is ~0.2 us, a loaded memory round trip 1-2 us: with the pieces of three fragments in flight (36 registers - the
+// main loop's operand fragments are dead here) the wave pays the latency once per tile, in the constants' wait, not once per fragment.
+#ifndef E4_DEPTH
+#define E4_DEPTH 1
+#endif
+template <int NF>
+struct E4Cnt {
+    static constexpr int NP = 16 * NF * 2;
+    static constexpr int LOADS = NP > 128 ? 3 : 2;       // asm loads per fragment (e4_load_res)
+    static constexpr int STORES = (NP + 63) / 64;        // 16-byte row stores per fragment (e4_fragment)
+};
+// GroupNorm-statistics writer bookkeeping of a wave tile whose fragments are CONSECUTIVE 16-row runs (v3 / v4 kernels, the 3x3 haloed kernel): the
+// statistics group of the current fragment and its first row inside it, advanced per fragment (called once per fragment, in order).  A writer
+// = the wave tile's run of rows inside one statistics group; slot = ceil(first row of the run inside the group / wave-tile rows).
+template <int WMR, int MF>
+struct E4GnRun {
+    unsigned sid, rem, sid0, rem0, rps;
+    __device__ __forceinline__ void init(long long mw0, long long gn_rps) {
+        rps = (unsigned)gn_rps;
+        sid0 = sid = rps ? e4_udiv((unsigned)mw0, rps) : 0u;
+        rem0 = rem = (unsigned)mw0 - sid * rps;
     }
+    // -> flush after this fragment?  (its group ends with it, or the tile does)
+    __device__ __forceinline__ bool step(int f, unsigned& slot, unsigned& sid_out) {
+        const unsigned first = sid == sid0 ? rem0 : 0u;
+        slot = (first + WMR - 1) / WMR;
+        sid_out = sid;
+        rem += 16;
+        const bool ends = rem >= rps;
+        if (ends) {
+            rem -= rps;
+            ++sid;
+        }
+        return f + 1 == MF || ends;
+    }
+};
+// retire the MF fragments of a finished wave tile; RowFn(f) = first output row of fragment f, FlushFn(f, m0f, slot&, sid&) = flush? of the
+// GroupNorm-statistics epilogue.  Residual pieces travel by value (a reference went through a stack array, see conv.hip halo_retire):
+// cur / n1 / n2 = the pieces of fragments F, F + 1, F + 2 (as far as E4_DEPTH reaches; the rest are dead values).
+// accumulator source: get<F>(out) hands over the NF fragments of row fragment F.  Register-array form (v3 kernels, conv.hip):
+template <int MF, int NF>
+struct E4AccArray {
+    f32x4 (&a)[MF][NF];
+    template <int F>
+    __device__ __forceinline__ void get(f32x4 (&out)[NF]) const {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) out[j] = a[F][j];
+    }
+};
+template <int F, int MF, int NF, bool GN, typename Acc, typename RowFn, typename FlushFn>
+__device__ __forceinline__ void e4_retire(const GP& p, const Acc& acc, long long nw0, int lane, unsigned char* stage, E4Res cur, E4Res n1, E4Res n2,
+                                          E4Tile<NF> t, GnAcc<GN ? NF : 1>& gn, RowFn rowfn, FlushFn flushfn) {
+    if constexpr (F < MF) {
+        constexpr int D = E4_DEPTH;
+        static_assert(D >= 1 && D <= 3, "residual look-ahead: 1..3 fragments");
+        const long long m0f = rowfn(F);
+        const bool has1 = p.res1 != nullptr;
+        E4Res n3 = n2;
+        if constexpr (F + D < MF) {
+            if (has1) e4_load_res<NF>(p, rowfn(F + D), nw0, lane, D == 1 ? n1 : (D == 2 ? n2 : n3));
+        }
+        if constexpr (F >= D) {
+            // pieces of fragment F: issued at the top of fragment F - D; behind them D fragments' stores and the loads of the fragments
+            // F + 1 .. F + D that exist (the prologue's pieces, F < D, landed in the constants' wait)
+            constexpr int younger_loads = (F + D < MF ? D : (MF - 1 - F > 0 ? MF - 1 - F : 0));
+            if (has1) e4_wait_cnt<D * E4Cnt<NF>::STORES + younger_loads * E4Cnt<NF>::LOADS>(cur);
+        }
+        bool regroup = false;
+        if constexpr (F > 0) {
+            // the fragment's first row inside the constants' row groups (fragments never straddle: the groups are multiples of 16 rows)
+            const unsigned d = (unsigned)(m0f - rowfn(F - 1));
+            t.add_rem += d;
+            t.coef_rem += d;
+            regroup = (p.add && t.add_rem >= (unsigned)p.add_rpg) || (p.coef && t.coef_rem >= (unsigned)p.coef_rpg);
+        }
+        if (regroup) {
+            // (rare: the wave tile straddles two row groups - the constants' vmcnt(0) lands the look-ahead pieces too and must name them)
+            e4_tile_consts<NF>(p, m0f, nw0, lane, t);
+            asm volatile("" : "+v"(n1.a0), "+v"(n1.a1), "+v"(n1.a2), "+v"(n2.a0), "+v"(n2.a1), "+v"(n2.a2), "+v"(n3.a0), "+v"(n3.a1), "+v"(n3.a2));
+        }
+        {
+            f32x4 accf[NF];
+            acc.template get<F>(accf);
+            e4_fragment<NF, GN>(p, accf, m0f, nw0, lane, stage, cur, t, gn);
+        }
+        if constexpr (GN) {
+            unsigned slot = 0, sid = 0;
+            if (flushfn(F, m0f, slot, sid)) gn_flush<NF>(p, gn, (long long)sid, nw0, lane, stage, slot);
+        }
+        e4_retire<F + 1, MF, NF, GN>(p, acc, nw0, lane, stage, n1, n2, n3, t, gn, rowfn, flushfn);
+    }
+}
+template <int MF, int NF, bool GN, typename Acc, typename RowFn, typename FlushFn>
+__device__ __forceinline__ void e4_retire_tile_src(const GP& p, const Acc& acc, long long nw0, int lane, unsigned char* stage, RowFn rowfn, FlushFn flushfn) {
+    constexpr int D = E4_DEPTH;
+    E4Res r0, r1, r2;
+    r0.a0 = r0.a1 = r0.a2 = u32x4{0u, 0u, 0u, 0u};
+    r1 = r0;
+    r2 = r0;
+    if (p.res1) {
+        e4_load_res<NF>(p, rowfn(0), nw0, lane, r0);
+        if constexpr (D >= 2 && MF > 1) e4_load_res<NF>(p, rowfn(1), nw0, lane, r1);
+        if constexpr (D >= 3 && MF > 2) e4_load_res<NF>(p, rowfn(2), nw0, lane, r2);
+    }
+    E4Tile<NF> t;
+    e4_tile_consts<NF>(p, rowfn(0), nw0, lane, t);          // (its vmcnt(0) also lands the residual pieces issued above)
+    asm volatile("" : "+v"(r0.a0), "+v"(r0.a1), "+v"(r0.a2), "+v"(r1.a0), "+v"(r1.a1), "+v"(r1.a2), "+v"(r2.a0), "+v"(r2.a1), "+v"(r2.a2));
+    GnAcc<GN ? NF : 1> gn;
+    if constexpr (GN) gn_zero(gn);
+    e4_retire<0, MF, NF, GN>(p, acc, nw0, lane, stage, r0, r1, r2, t, gn, rowfn, flushfn);
 }
 template <int MF, int NF, bool GN, typename RowFn, typename FlushFn>
 __device__ __forceinline__ void e4_retire_tile(const GP& p, f32x4 (&acc)[MF][NF], long long nw0, int lane, unsigned char* stage, RowFn rowfn, FlushFn flushfn) {
-    E4Res cur;
-    cur.a0 = cur.a1 = cur.a2 = u32x4{0u, 0u, 0u, 0u};
-    if (p.res1) e4_load_res<NF>(p, rowfn(0), nw0, lane, cur);
-    E4Tile<NF> t;
-    e4_tile_consts<NF>(p, rowfn(0), nw0, lane, t);          // (its vmcnt(0) also lands the residual pieces of fragment 0)
-    asm volatile("" : "+v"(cur.a0), "+v"(cur.a1), "+v"(cur.a2));
-    GnAcc<GN ? NF : 1> gn;
-    if constexpr (GN) gn_zero(gn);
-    e4_retire<0, MF, NF, GN>(p, acc, nw0, lane, stage, cur, t, gn, rowfn, flushfn);
+    e4_retire_tile_src<MF, NF, GN>(p, E4AccArray<MF, NF>{acc}, nw0, lane, stage, rowfn, flushfn);
 }
 
 // ---- stream-K tail ------------------------------------------------------------------------------------------------------------------------

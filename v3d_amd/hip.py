@@ -118,8 +118,9 @@ def _ptr(t: Optional[torch.Tensor]):
 class HipOps(OpsBase):
     name = "hip"
 
-    def __init__(self, device: Optional[torch.device] = None):
-        self.lib = load_library()
+    def __init__(self, device: Optional[torch.device] = None, lib_path: Optional[str] = None):
+        # lib_path: another build of the library (tools/mainloop_ab.py interleaves several builds in ONE process: same box, same clocks)
+        self.lib = load_library(lib_path or LIB_PATH)
         if not torch.cuda.is_available():
             raise RuntimeError("v3d_amd: no HIP device visible (torch.cuda.is_available() is False); the V3D hot path "
                                "has no CPU fallback")
