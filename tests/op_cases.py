@@ -575,7 +575,7 @@ def all_cases(full: bool = True):
         # 48 tiles of 40 chunks on 256 CUs: stream-K tail with five or six blocks per tile (one owner piece + several donors, added in block order)
         ("conv_gn_16_streamk_many_donors", case_conv_gn, dict(N=320, C1=1280, conv=(36, 16, 16), res=1, gn_out=True, seed=10, expect_streamk=True), TOL_BF16),
         ("conv_gn_64_offcentre", case_conv_gn, dict(N=320, C1=64, conv=(3, 64, 64), mean=30.0, seed=5), TOL_BF16),
-        ("conv_gn_nosilu", case_conv_gn, dict(N=320, C1=32, conv=(3, 32, 32), silu=False, seed=6), TOL_BF16),
+        ("conv_gn_nosilu", case_conv_gn, dict(N=320, C1=32, conv=(3, 32, 32), silu=False, seed=6, expect_fused=False), TOL_BF16),
         ("conv_gn_unsupported_8x8", case_conv_gn, dict(N=1280, C1=64, conv=(36, 8, 8), expect_fused=False), TOL_BF16),
         ("convt_gn_T6", case_conv_gn, dict(N=320, C1=64, convt=(2, 6, 1024), res=1, coef=True, seed=7), TOL_BF16),
         ("convt_gn_T18_add_gnout", case_conv_gn, dict(N=320, C1=96, convt=(2, 18, 256), add=True, gn_out=True, seed=8), TOL_BF16),

@@ -315,7 +315,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         constexpr int NOPS = HPW * 4 * 15;
         if constexpr (XF && OP >= 0 && OP < NOPS) {
             constexpr int pr = OP / 15, st = OP % 15, v = pr / 4, e = pr % 4;
-            const bool silu_on = p.gn_in_silu != 0;
             if constexpr (st == 0) {
                 xs.x0 = bflo(xs.raw[e]); asm volatile("" : "+v"(xs.x0));
             } else if constexpr (st == 1) {
@@ -343,9 +342,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             } else if constexpr (st == 11) {
                 xs.t1 = __builtin_amdgcn_rcpf(xs.t1); asm volatile("" : "+v"(xs.t1));
             } else if constexpr (st == 12) {
-                xs.y0 = silu_on ? xs.y0 * xs.t0 : xs.y0; asm volatile("" : "+v"(xs.y0));
+                xs.y0 = xs.y0 * xs.t0; asm volatile("" : "+v"(xs.y0));      // (SiLU always: the host refuses a bare norm)
             } else if constexpr (st == 13) {
-                xs.y1 = silu_on ? xs.y1 * xs.t1 : xs.y1; asm volatile("" : "+v"(xs.y1));
+                xs.y1 = xs.y1 * xs.t1; asm volatile("" : "+v"(xs.y1));
             } else {
                 { unsigned pk = pack2bf(xs.y0, xs.y1); asm volatile("" : "+v"(pk)); xs.out[e] = pk; }
                 if constexpr (e == 3) {
@@ -472,6 +471,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                     asm volatile("" : "+v"(fb));
 #pragma unroll
                     for (int i = 0; i < MF; ++i) {
+                        // (A/B, profiles/r04_mainloop_ab.txt: switching the SCALAR part of the address instead - a zero page as large as a fragment's
+                        // pixel range, one v_add per fragment - removes 2 v_readlane + 1 v_cndmask per fragment and step and measured 4-8 % SLOWER)
                         unsigned a = fb + foff(i);
                         if (HM == HM_CONV && dy != 1) {
                             const bool ok = (vmask >> (2 * i + (dy == 2 ? 1 : 0))) & 1u;
@@ -618,6 +619,7 @@ int v3d_conv_halo_variant(const V3dGemmParams& p, int mode) {
     if (p.res2 && (!al(p.res2, 8) || p.ldr2 % 4)) return 0;
     if (p.bias && !al(p.bias, 16)) return 0;
     if (p.gn_in && (p.gn_in_rps <= 0 || !al(p.gn_in, 16))) return 0;
+    if (p.gn_in && !p.gn_in_silu) return 0;                         // the operand path applies GroupNorm + SiLU (every ResBlock half); a bare norm keeps the apply pass
     if (p.gn_stats && (80 % p.gn_cpg || p.gn_rps % 16)) return 0;
     if (mode == V3D_GEMM_CONV3X3) {
         if (p.stride != 1 || p.upshift != 0 || p.pad_lo != 1 || p.Hin != p.Hout || p.Win != p.Wout) return 0;
