@@ -110,11 +110,15 @@ def test_scene_shape_vs_oracle():
     # cosine >= 0.998 and max rel <= 8e-2 (e4m3 has 3 mantissa bits: 6 % per element, averaged down by the 64-wide dot products and the
     # residual stream; the bf16 path above holds 0.999 / 4e-2), and the fp8 result must stay close to the bf16 one.
     import os
+    prev_fp8 = os.environ.get("V3D_ATTN_FP8")
     os.environ["V3D_ATTN_FP8"] = "1"
     try:
         out8 = net(x8.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi.to(DEV)).float().cpu()
     finally:
-        os.environ["V3D_ATTN_FP8"] = "0"
+        if prev_fp8 is None:
+            os.environ.pop("V3D_ATTN_FP8", None)
+        else:
+            os.environ["V3D_ATTN_FP8"] = prev_fp8
     rel8, cos8 = rel_cos(out8, ref)
     relb, cosb = rel_cos(out8, out)
     record_parity("scene_shape_unet_eval_width64_fp8_attention", {"max_rel_err": round(rel8, 5), "cosine": round(cos8, 6), "vs_bf16_max_rel": round(relb, 5),

@@ -1165,7 +1165,12 @@ extern "C" int v3d_gemm(const v3d_gemm_args* a, v3d_stream_t stream) {
     const int frc = fill_params(a, p, &halo);
     if (frc != V3D_OK) return frc;
     hipStream_t st = (hipStream_t)stream;
-    if (halo) return v3d_conv_halo_launch(p, halo, stream);       // (its epilogue gathers gn_stats itself)
+    if (halo) {
+        const int rc = v3d_conv_halo_launch(p, halo, stream);     // (its epilogue gathers gn_stats itself ...
+        // ... unless the A/B knob V3D_GEMM_GN_EPILOGUE=0 took the request out of the parameter block: then the stand-alone pass runs here too)
+        if (rc != V3D_OK || !a->gn_stats || p.gn_stats) return rc;
+        return v3d_groupnorm_stats(a->out, a->N, nullptr, 0, a->gn_stats, a->gn_nslots, a->M / a->gn_rps, a->gn_rps, 32, 1, stream);
+    }
     V3D_REQUIRE(!a->gn_in_table, "v3d_gemm: gn_in_table is set but this shape is not one of the LDS-haloed kernels' (v3d_gemm_gn_in_supported): "
                                  "normalise the input with v3d_groupnorm_apply first");
     if (p.gn_stats || a->gn_stats) {

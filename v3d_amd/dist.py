@@ -126,9 +126,12 @@ class FrameShard:
         finally:
             _ACTIVE = prev
             self.context_frame0 = prev_ctx
+            if prev is not self:
+                self._bufs.clear()       # the split-halo buffers (up to ~1 GB at the decoder's 512 x 512 levels) live for one sharded run, not for the process
 
     # ---- communication primitives (a test subclass stages them through the host) -------------------------
     def _peer(self, r: int) -> int:
+        """shard rank -> rank of the process group the exchanges run on (subclasses add addresses outside the shard, e.g. PARTNER)"""
         return self.ranks[r]
 
     def _allreduce_sum(self, t: torch.Tensor) -> None:
@@ -298,6 +301,11 @@ class HybridShard(FrameShard):
         super().__init__(T_global, ranks=list(range(self.cfg_index * F, (self.cfg_index + 1) * F)))
         self.partner = (1 - self.cfg_index) * F + self.rank            # global rank holding the other cfg half of MY frames
 
+    PARTNER = -1      # address of the rank holding the other cfg half of my frames, for the ordinary exchange primitive
+
+    def _peer(self, r: int) -> int:
+        return self.partner if r == self.PARTNER else self.ranks[r]
+
     def describe(self) -> str:
         return "cfg2 x (" + "+".join(str(len(p)) for p in self.parts) + ")"
 
@@ -305,11 +313,7 @@ class HybridShard(FrameShard):
         """mine [(b T_local), ...] = my half of the guided batch's network output -> [uc rows ; c rows] (guiders.py:95 order)."""
         mine = mine.contiguous()
         other = torch.empty_like(mine)
-        self.ranks.append(self.partner)               # (address the partner through the ordinary exchange primitive: shard rank `world`)
-        try:
-            self._exchange([(mine, self.world)], [(other, self.world)])
-        finally:
-            self.ranks.pop()
+        self._exchange([(mine, self.PARTNER)], [(other, self.PARTNER)])
         return torch.cat([mine, other] if self.cfg_index == 0 else [other, mine], dim=0)
 
 

@@ -131,6 +131,21 @@ class HipOps(OpsBase):
         if self.wave_size != 64:
             raise RuntimeError(f"v3d_amd kernels are wave64 gfx950 code; device reports wave size {self.wave_size}")
 
+    # ---- health ----------------------------------------------------------------------------------
+    def streamk_timeouts(self) -> int:
+        """Stream-K hand-offs of this process that gave up waiting for a donor block (gemm_common.h sk_gather: bounded spin).  Never expected:
+        every block of a persistent launch is resident.  A non-zero count means a tile was retired without a donor's partial sums - callers that
+        care about the numbers (bench.py, the entry script, smoke()) check it after their work and fail loudly.  Synchronises the device."""
+        fn = self.lib.v3d_debug_sk_timeouts
+        fn.restype, fn.argtypes = C.c_longlong, []
+        return int(fn())
+
+    def check_health(self):
+        n = self.streamk_timeouts()
+        if n:
+            raise RuntimeError(f"v3d_amd: {n} stream-K hand-off(s) timed out in this process (a donor block was not co-resident): results of the "
+                               "affected launches are wrong; rerun with V3D_STREAMK=0 and report the configuration")
+
     # ---- plumbing ---------------------------------------------------------------------------------
     def _check(self, rc: int, what: str):
         if rc != 0:

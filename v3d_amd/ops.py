@@ -214,7 +214,8 @@ class OpsBase:
             out = self.empty((n_img * S, C), self.act_dtype, x1.device)
         if tuple(out.shape) != (n_img * S, C):
             raise ValueError(f"groupnorm: out has shape {tuple(out.shape)}, the normalised tensor is [{n_img * S}, {C}]")
-        if table is None and stats is None and stats_hook is None and self.groupnorm_small_fits(x1, x2, S, imgs_per_stat, groups):
+        if (table is None and stats is None and stats_hook is None and (count_imgs is None or count_imgs == imgs_per_stat)
+                and self.groupnorm_small_fits(x1, x2, S, imgs_per_stat, groups)):
             # small statistics groups (8 x 8 level, the 16 x 16 level's transformer norms): one launch instead of three launch-bound ones
             return self.groupnorm_small(x1, x2, gamma, beta, out, n_img, S, eps=eps, silu=silu, imgs_per_stat=imgs_per_stat, groups=groups)
         if table is None:
