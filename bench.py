@@ -385,6 +385,117 @@ def parity_rollout(device, lat=32):
     return out
 
 
+def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
+    """bench.py --shard-sim N: what ONE GPU of an N-GPU frame-sharded run (BASELINE.json configs[2] / [3]) COMPUTES, measured on this one GPU.
+    A SimFrameShard (v3d_amd/dist.py) plays the rank with the most frames (rank 0) and the rank with the fewest (rank N - 1) with
+    self-fed halos / K|V / statistics: the same kernels, tile counts and buffer sizes as inside the real run, no communication.  Reported per
+    rank: ms per guided U-Net evaluation and per decode (from two sharded samples of 2 and 6 EDM steps), the GEMM-family launches whose
+    tiles do not fill the CUs and their share of the GEMM time, the bytes and grouped point-to-point calls the real exchanges would carry; and
+    against the unsharded sample on the same GPU: the compute-only strong-scaling ceiling.  NO RCCL TIMING EXISTS FOR THIS PATH (one GPU
+    per build box): the ceiling assumes free communication."""
+    from v3d_amd.dist import SimFrameShard, sharded_sample
+    from v3d_amd.ops import get_ops
+    from v3d_amd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    N = args.shard_sim
+    ops = get_ops()
+    cus = ops.cu_count
+
+    def sampler_of(steps):
+        return EulerEDMSampler(discretization_config={"target": P + "discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}}, num_steps=steps,
+                               guider_config={"target": P + "guiders.LinearPredictionGuider", "params": {"max_scale": CFG, "min_scale": CFG, "num_frames": T_FRAMES}},
+                               device=device)
+
+    def wall(fn, reps=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def fill_of(g):
+        """Fraction of the CU slots the launch keeps busy over its rounds, mirroring the dispatch of v3d_amd/csrc/gemm.hip: persistent 192 x 320 /
+        256 x 256 tiles (one block per CU; the haloed convolutions share their last round out, stream-K) where they fill the chip about as well
+        as the 128 x 128 / 128 x 64 tiles of the two-blocks-per-CU kernels, else those."""
+        cdiv = lambda a, b: -(-a // b)
+        if g.gn_in is not None:
+            return 1.0 if cdiv(g.M, 192) * cdiv(g.N, 320) >= cus // 2 else cdiv(g.M, 192) * cdiv(g.N, 320) / cus
+        if g.geglu and cdiv(g.M, 256) * cdiv(g.N, 128) >= 2 * cus:
+            nt = cdiv(g.M, 256) * cdiv(g.N, 128)
+            return nt / (cdiv(nt, 2 * cus) * 2 * cus)
+        bm, bn = (192, 320) if (g.N % 320 == 0 and not g.geglu) else (256, 256)
+        nt3 = cdiv(g.M, bm) * cdiv(g.N, bn)
+        fill3 = nt3 / (cdiv(nt3, cus) * cus) * (g.N / (cdiv(g.N, bn) * bn))
+        w128, w64 = cdiv(g.N, 128) * 128, cdiv(g.N, 64) * 64
+        wv2 = min(w64, w128)
+        nt2 = cdiv(g.M, 128) * (wv2 // (64 if w64 < w128 else 128)) * max(1, g.batch)
+        fill2 = nt2 / (cdiv(nt2, 2 * cus) * 2 * cus) * (g.N / wv2)
+        return fill3 if (fill3 >= 0.9 * fill2 and g.batch == 1 and g.N >= 256 and g.K % 32 == 0) else fill2
+
+    def run(rank):
+        sh = SimFrameShard(T_FRAMES, N, rank) if N > 1 else None
+        s2, s6 = sampler_of(2), sampler_of(6)
+        extra = {"image_only_indicator": torch.zeros(2, T_FRAMES, device=device), "num_video_frames": T_FRAMES}
+
+        def sample(smp):
+            if sh is None:
+                z = smp(lambda i, sg, cc: denoiser(wrapped, i, sg, cc, **extra), noise.clone(), cond=c, uc=uc)
+                return dec(z * (1.0 / 0.18215), timesteps=T_FRAMES)
+            return sharded_sample(sh, smp, denoiser, wrapped, lambda z: dec(z * (1.0 / 0.18215), timesteps=sh.T_local), noise.clone(), c, uc, B=1, gather=False)
+
+        t2, t6 = wall(lambda: sample(s2)), wall(lambda: sample(s6))
+        ev = (t6 - t2) / 4.0
+        decode = t2 - 2.0 * ev
+        # one instrumented 2-step sample: GEMM-family launches by tile fill
+        rec = []
+        orig = ops.gemm
+
+        def timed_gemm(g):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(g)
+            e1.record()
+            rec.append((fill_of(g), e0, e1))
+            return r
+        ops.gemm = timed_gemm
+        b0, x0 = (sh.bytes_sent, sh.n_exchanges) if sh else (0, 0)
+        try:
+            sample(s2)
+            torch.cuda.synchronize()
+        finally:
+            ops.__dict__.pop("gemm", None)
+        tot = sum(a.elapsed_time(b) for _, a, b in rec)
+        under = [ms for f, ms in ((f, a.elapsed_time(b)) for f, a, b in rec) if f < 0.75]
+        half = [ms for f, ms in ((f, a.elapsed_time(b)) for f, a, b in rec) if f < 0.5]
+        out = {"frames": sh.T_local if sh else T_FRAMES, "ms_per_unet_eval": round(ev, 2), "ms_per_decode": round(decode, 2),
+               "ms_per_sample_25_steps_compute_only": round(STEPS * ev + decode, 1),
+               "gemm_launches_per_2_step_sample": len(rec), "launches_filling_under_75pct_of_the_cu_slots": len(under), "their_share_of_gemm_time": round(sum(under) / max(tot, 1e-9), 3),
+               "launches_filling_under_50pct": len(half), "their_share_of_gemm_time_50pct": round(sum(half) / max(tot, 1e-9), 3)}
+        if sh:
+            nb, nx = sh.bytes_sent - b0, sh.n_exchanges - x0
+            # the 2-step sample = 2 evaluations + 1 decode: per-evaluation figures from the U-Net part only would need a second counter; report the sample's
+            out["exchange_MB_per_2_step_sample_incl_decode"] = round(nb / 1e6, 1)
+            out["grouped_p2p_calls_per_2_step_sample_incl_decode"] = nx
+        return out
+
+    base = run(0) if N == 1 else None
+    if N > 1:
+        keep = args.shard_sim
+        args.shard_sim = 1
+        base = shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc)["unsharded"]
+        args.shard_sim = keep
+    if N == 1:
+        return {"unsharded": base}
+    r_first, r_last = run(0), run(N - 1)
+    slow = max(r_first["ms_per_sample_25_steps_compute_only"], r_last["ms_per_sample_25_steps_compute_only"])
+    return {"world": N, "cus": cus, "unsharded": base, "rank_0": r_first, f"rank_{N - 1}": r_last,
+            "ideal_speedup_most_loaded_rank": round(T_FRAMES / r_first["frames"], 2),
+            "compute_only_strong_scaling_ceiling": round(base["ms_per_sample_25_steps_compute_only"] / slow, 2),
+            "note": "compute of one rank on one GPU with self-fed halos / K|V / statistics (v3d_amd/dist.py SimFrameShard); communication is NOT timed - "
+                    "no RCCL run of this path exists (one GPU per build box)"}
+
+
 def build_models_sampler(device):
     from v3d_amd.sgm.modules.diffusionmodules.denoiser import Denoiser
     from v3d_amd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
@@ -418,6 +529,9 @@ def main():
     ap.add_argument("--no-parity-rollout", action="store_true")
     ap.add_argument("--shard-timeout", dest="shard_timeout", type=float, default=240.0,
                     help="N > 1 replica mode: seconds the secondary frame-sharded run may take before the line is printed without it")
+    ap.add_argument("--shard-sim", dest="shard_sim", type=int, default=0,
+                    help="N: measure on THIS GPU what rank 0 (most frames) and rank N-1 (fewest) of an N-GPU frame-sharded run compute per evaluation / decode "
+                         "(self-fed exchanges, no communication) and the compute-only strong-scaling ceiling; prints its own JSON line and exits")
     ap.add_argument("--graph", action="store_true",
                     help="replay captured HIP graphs of the network evaluation / decode instead of launching from Python "
                          "(measured 9.59 vs 9.62 frames/s: ROCm 7.2 graph replay does not close the launch gaps, so it is off by default)")
@@ -450,6 +564,14 @@ def main():
     shard_mode = args.shard in ("frames", "hybrid") and world > 1
     # replica mode: every rank generates its own sample (different seed per rank); frame-shard mode: ONE sample, same inputs everywhere
     noise, c, uc = synth.synthetic_conditioning(T_FR, LH, LW, seed=23 + (0 if shard_mode else rank), device=device, batch=B_IN)
+    if args.shard_sim:
+        if world > 1 or scene or B_IN != 1:
+            raise SystemExit("--shard-sim runs on one GPU, headline shapes, one input")
+        res = shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc)
+        print(json.dumps({"metric": f"frame-shard compute simulation, V3D_512 18-frame sample over {args.shard_sim} GPUs (one GPU measured)", "n_gpus": 1,
+                          "dtype": "bf16", "data": "synthetic", "config": {"workload": "BASELINE.json configs[2]/[3] sub-problem of one rank: V3D_512, 18 frames "
+                          f"sharded over {args.shard_sim} ranks, 64x64 latents, guided batch of 2, 18-frame decode"}, "shard_sim": res}), flush=True)
+        return
     shard = None
     if world > 1:
         from v3d_amd.dist import FrameShard, HybridShard

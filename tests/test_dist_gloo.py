@@ -100,6 +100,67 @@ def test_two_rank_uneven_frame_shard_matches_unsharded():
         assert sent > 0
 
 
+def _worker_inputs2(rank, world, port, q):
+    """BASELINE.json configs[3] runs a BATCH of inputs under the frame shard: two inputs -> a guided batch of 4 samples per evaluation, every
+    exchange (K|V, halos + fp64 GroupNorm sums, the gather of the decoded frames) carries all samples of the rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    torch.set_grad_enabled(False)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.ops_emul import EmulOps
+        from tiny import build_denoiser, build_sampler
+        from v3d_amd import synth
+        from v3d_amd.dist import FrameShard, sharded_sample
+        from v3d_amd.engine.vae import run_decoder
+        from v3d_amd.ops import use_backend
+        from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+        p = TINY
+        T, B = p["T"], 2
+        noise, c, uc = synth.synthetic_conditioning(T, p["H"], p["W"], seed=7, batch=B)
+        with use_backend(EmulOps("cpu", exact=True)):
+            net, dec = build_unet(), build_decoder()
+            sampler, den, wr = build_sampler(T, steps=2), build_denoiser(), OpenAIWrapper(net)
+            extra = {"image_only_indicator": torch.zeros(2 * B, T), "num_video_frames": T}
+            z_full = sampler(lambda i, s, cc: den(wr, i, s, cc, **extra), noise.clone(), cond=c, uc=uc)
+            f_full = dec(z_full[:, :, :8, :8].contiguous(), timesteps=T)
+            sh = FrameShard(T)
+            f_sh = sharded_sample(sh, sampler, den, wr, lambda zl: run_decoder(dec.packed(), zl[:, :, :8, :8].contiguous(), sh.T_local, shard=sh),
+                                  noise.clone(), c, uc, B=B)
+            assert f_sh.shape == f_full.shape == (B * T, 3, 64, 64), (tuple(f_sh.shape), tuple(f_full.shape))
+            err = ((f_sh - f_full).abs().max() / f_full.abs().max()).item()
+            # the two inputs must really differ (a sample mix-up between inputs would otherwise go unnoticed)
+            assert (f_full[:T] - f_full[T:]).abs().max() > 1e-3
+        q.put((rank, sh.T_local, err, sh.bytes_sent))
+    except Exception as e:
+        import traceback
+        q.put((rank, -1, traceback.format_exc(), str(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_frame_shard_batch_of_two_inputs_matches_unsharded():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_inputs2, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    for r in res:
+        assert r[1] >= 0, f"rank {r[0]} failed:\n{r[2]}"
+    res.sort()
+    assert [r[1] for r in res] == [2, 1]
+    for rank, _, err, sent in res:
+        assert err <= 5e-5, f"rank {rank}: sharded sampler + decode of a 2-input batch differs from the unsharded run: {err}"
+        assert sent > 0
+
+
 def _worker8(rank, world, port, q, T):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -222,3 +283,30 @@ def test_hybrid_cfg_parallel_x_frame_shard_matches_unsharded(world, T, split):
     assert res[0][3] <= 2e-4, f"hybrid-sharded 2-step sampler vs unsharded: {res[0][3]}"
     for r in res:     # 2 evaluations x (44 + 16 grouped calls + 1 cfg swap) + the output gather
         assert r[5]["all_reduces"] == 0 and r[5]["grouped_p2p_calls"] <= 2 * 61 + 1, r[5]
+
+
+def test_sim_frame_shard_plays_one_rank_without_communication():
+    """bench.py --shard-sim: SimFrameShard runs one rank's share of a sharded sample in ONE process (no process group): same call structure as
+    the real shard (grouped calls and bytes are counted), local shapes, finite results."""
+    from oracle.ops_emul import EmulOps
+    from tiny import build_denoiser, build_sampler
+    from v3d_amd import synth
+    from v3d_amd.dist import SimFrameShard, sharded_sample
+    from v3d_amd.engine.vae import run_decoder
+    from v3d_amd.ops import use_backend
+    from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
+    torch.set_grad_enabled(False)
+    p = TINY
+    T = p["T"]
+    noise, c, uc = synth.synthetic_conditioning(T, p["H"], p["W"], seed=7)
+    with use_backend(EmulOps("cpu", exact=True)):
+        net, dec = build_unet(), build_decoder()
+        sampler, den, wr = build_sampler(T, steps=2), build_denoiser(), OpenAIWrapper(net)
+        for rank, frames in ((0, 2), (1, 1)):
+            sh = SimFrameShard(T, 2, rank)
+            assert sh.T_local == frames and sh.world == 2 and sh.first == (rank == 0) and sh.last == (rank == 1)
+            out = sharded_sample(sh, sampler, den, wr, lambda zl: run_decoder(dec.packed(), zl[:, :, :8, :8].contiguous(), sh.T_local, shard=sh),
+                                 noise.clone(), c, uc, B=1, gather=False)
+            assert out.shape == (frames, 3, 64, 64) and torch.isfinite(out).all()
+            assert sh.n_exchanges > 0 and sh.bytes_sent > 0
+            assert not sh._bufs, "the split-halo buffers of a sharded run are released when it ends"

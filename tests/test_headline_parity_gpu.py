@@ -5,6 +5,8 @@ loop, against the fp32 CPU oracle (oracle/sgm_oracle.py, pinned to the reference
                                            benchmark's own network, every denoiser call teacher-forced against the oracle (3-D GroupNorm
                                            over 18 frames, 18-token temporal attention at 8192 x 5 problems, the persistent 147456-row
                                            GEMM tiles) + the final latent.
+  * test_headline_midschedule_eval_vs_oracle  the same network teacher-forced at steps 8 / 14 / 20 of the 25-step schedule (sigma 70.5 / 6.35 /
+                                           0.157, where the network output carries the denoised image), one sample of the doubled batch each.
   * test_headline_decoder_T18_vs_oracle    the decode half at its own size: full-width VideoDecoder, T = 18, 64 x 64 -> 512 x 512.
   * test_rollout_25_steps_cosine_and_psnr  SURVEY.md 8d end-to-end bar at width 64: T = 18, 64 x 64 latents, 25 EulerEDM steps,
                                            LinearPredictionGuider 4.5, DiffusionEngine.decode_first_stage -> 512 x 512 frames:
@@ -97,6 +99,47 @@ def test_headline_rollout_3_steps_vs_oracle(full_unet):
     assert cos_z >= 0.999 and rel_z <= 0.1, (rel_z, cos_z)
 
 
+@pytest.mark.parametrize("step", [8, 14, 20])
+def test_headline_midschedule_eval_vs_oracle(full_unet, step):
+    """Teacher-forced full-width evaluations at MID-SCHEDULE noise levels of the headline 25-step schedule (the 3-step rollout
+    above only visits sigma = 700, 15.6 and 0.002 - at the last one c_skip ~ 1 and the network output hardly matters).  Steps 8 / 14 / 20 of
+    EDMDiscretization(25 steps, sigma_max 700) are sigma = 70.5 / 6.35 / 0.157: c_out * F(x) carries most of the denoised image there.
+    The HIP path evaluates the cfg-doubled 36-image batch exactly as the sampler would (Denoiser x OpenAIWrapper x VideoUNet at width 320,
+    T = 18, 64 x 64); the fp32 oracle re-evaluates ONE of the two samples of that batch on the same inputs (the unconditional half at steps
+    8 and 20, the conditional one at step 14: samples do not interact, so half the batch is an exact check of that half at half the CPU
+    time, ~60 s).  Input: a unit-variance latent + sigma * noise, the state the sampler holds at that step."""
+    from oracle import sgm_oracle as O
+    T, H, W = 18, 64, 64
+    sig = float(O.edm_sigmas(25, sigma_max=700.0)[step])
+    noise, c, uc = synth.synthetic_conditioning(T, H, W, seed=31 + step)
+    g = torch.Generator().manual_seed(100 + step)
+    x = torch.randn(T, 4, H, W, generator=g) + sig * noise
+    xin = torch.cat([x, x])
+    s_in = torch.full((2 * T,), sig)
+    cc = {k: torch.cat([uc[k], c[k]]) for k in c}
+    den, wr = build_denoiser(), OpenAIWrapper(full_unet)
+    extra = {"image_only_indicator": torch.zeros(2, T, device=DEV), "num_video_frames": T}
+    out = den(wr, xin.to(DEV), s_in.to(DEV), to_dev(cc, DEV), **extra).float().cpu()
+    assert out.shape == (2 * T, 4, H, W) and torch.isfinite(out).all()
+    half = (step // 2) % 2                                     # 0 = unconditional rows (steps 8, 20), 1 = conditional rows (step 14) of the doubled batch
+    rows = slice(half * T, (half + 1) * T)
+    sd = {k: v.detach().float().cpu() for k, v in full_unet.state_dict().items()}
+    ucfg, ioi = synth.unet_config(320), torch.zeros(1, T)
+    t0 = time.time()
+    ref = O.denoise(lambda x8, cn, ctx, vec: O.unet_forward(sd, ucfg, x8, cn, ctx, vec, T, ioi), xin[rows], s_in[rows], {k: v[rows] for k, v in cc.items()})
+    dt = time.time() - t0
+    rel, cos = rel_cos(out[rows], ref)
+    per_img = min(rel_cos(out[rows][k], ref[k])[1] for k in range(T))
+    # how much of the denoised output is the network's (vs c_skip * x): ||c_out F|| / ||denoised||
+    c_skip = 1.0 / (sig * sig + 1.0)
+    net_share = float((ref - c_skip * xin[rows]).norm() / ref.norm())
+    record_parity(f"headline_midschedule_eval_step{step}", {"sigma": round(sig, 4), "half": "cond" if half else "uncond", "images_checked": T, "width": 320,
+                                                           "latent": [H, W], "max_rel_err": round(rel, 5), "cosine": round(cos, 6),
+                                                           "min_per_image_cosine": round(per_img, 6), "network_share_of_output": round(net_share, 4),
+                                                           "oracle_seconds": round(dt, 1)})
+    assert rel <= 4e-2 and cos >= 0.999 and per_img >= 0.998, (step, sig, rel, cos, per_img)
+
+
 def test_headline_decoder_T18_vs_oracle():
     """The decode half of the headline benchmark at its own size: full-width VideoDecoder (128 base channels), T = 18 frames,
     64 x 64 latents -> 512 x 512 - the 3-D GroupNorm over 18 x 512^2 x 128 channels (6 x 10^8 elements per group: statistics in
@@ -173,6 +216,14 @@ def test_rollout_25_steps_cosine_and_psnr():
 
 @pytest.mark.parametrize("kind,key", SAMPLER_FIXTURES)
 def test_sampler_steps_teacher_forced(golden, kind, key):
+    """Why `sampler_heun_central` sits at cosine 0.9964 / max rel 0.125 against the reference fixture while every other record is >= 0.999
+    (VERDICT r3): nothing in that run is less accurate per evaluation - part (1) below holds every one of its 5 denoiser calls to the
+    one-evaluation bound (<= 4e-2, cosine >= 0.999) on the trajectory's own inputs, part (2) holds the guider / Heun arithmetic to 2e-5.  The
+    trajectory-level number is that per-call error times the amplification of the sampler: the CentralPredictionGuider scales (c - uc) by up
+    to 2 * max_scale = 7 at the middle frames (a per-evaluation error e becomes up to (1 + 2 * 7) e in the guided prediction), and Heun's
+    corrector divides a difference of two nearly equal states by next_sigma (|dt| / (2 next_sigma) = 3900 for the 15.59 -> 0.002 step of the
+    3-step tiny schedule).  The bf16-mode EMULATOR (torch arithmetic, same rounding points) sits at the same distance from the fp32 fixture
+    (rel 0.12 / cosine 0.9964), and the HIP run is compared with it in part (3): the number is a property of bf16 x this sampler, not of a kernel."""
     from oracle import sgm_oracle as O
     from oracle.ops_emul import EmulOps
     from v3d_amd.ops import use_backend

@@ -90,6 +90,9 @@ class FrameShard:
             self.ranks = list(ranks)
             self.group = None
             self.rank = self.ranks.index(dist.get_rank())
+        self._setup(T_global)
+
+    def _setup(self, T_global: int):
         self.world = len(self.ranks)
         if self.world > T_global:
             raise ValueError(f"cannot shard {T_global} frames over {self.world} ranks")
@@ -282,6 +285,41 @@ class FrameShard:
         tmax = Tl - 1 if self.last else Tl
         outs = [ops.tmix_small(buf[bi].reshape((Tl + 2) * S, -1), w, b, 1, Tl, S, out_ch, tmin, tmax, row0=S) for bi in range(B)]
         return torch.cat(outs, dim=0) if B > 1 else outs[0]
+
+
+class SimFrameShard(FrameShard):
+    """MEASUREMENT ONLY (bench.py --shard-sim): one process plays rank `rank` of a `world`-way frame shard with NO communication.  Every
+    receive buffer of an exchange is fed from the rank's own data (halo frames <- its own boundary frames, the other ranks' K|V rows <- its own
+    rows repeated, the other ranks' fp64 GroupNorm sums <- its own), so the rank launches exactly the kernels, tile counts and buffer sizes
+    it would launch inside a real `world`-GPU run - what one GPU of an 8-GPU node COMPUTES per evaluation - while bytes and grouped calls are
+    counted as in the real exchange.  The numbers it produces are not a shard of any real sample."""
+
+    def __init__(self, T_global: int, world: int, rank: int):
+        self.group = None
+        self.ranks = list(range(world))
+        self.rank = rank
+        self._setup(T_global)
+
+    def _allreduce_sum(self, t: torch.Tensor) -> None:
+        self.n_allreduce += 1
+        t.mul_(self.world)
+
+    def _exchange(self, sends, recvs, async_op: bool = False) -> _Handle:
+        self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
+        self.n_exchanges += 1 if (sends or recvs) else 0
+        src = sends[0][0].reshape(-1) if sends else None
+        for t, _ in recvs:
+            if src is None or src.dtype != t.dtype:
+                t.zero_()
+                continue
+            flat = t.reshape(-1) if t.is_contiguous() else None
+            n = t.numel()
+            rep = src if src.numel() >= n else src.repeat((n + src.numel() - 1) // src.numel())
+            if flat is not None:
+                flat.copy_(rep[:n])
+            else:
+                t.copy_(rep[:n].reshape(t.shape))
+        return _Handle(())
 
 
 class HybridShard(FrameShard):
