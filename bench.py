@@ -49,7 +49,7 @@ PEAK_HBM_GBPS = 8000.0
 RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)      # 312.5: launches below it are HBM-bound (classified per launch)
 F_UNET_TFLOP = 45.677          # algorithmic FLOPs of one denoiser evaluation (reference graph, cfg batch 36)
 F_VAE_TFLOP_PER_FRAME = 3.043
-PMC_PROFILE = "r03_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
+PMC_PROFILE = "r04_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
 
 T_FRAMES, STEPS, CFG, LAT = 18, 25, 4.5, 64
 P = "v3d_amd.sgm.modules.diffusionmodules."

@@ -112,7 +112,8 @@ typedef struct v3d_gemm_args {
      * table [n_stat][K][2] fp32, gn_in_rows = its n_stat.  A2 != NULL: the input is the channel concatenation A[:, :K1] | A2[:, :K - K1]
      * (th.cat([h, hs.pop()], 1) of the U-Net's up path, video_model.py:483, never materialised), row stride lda2, same row count.
      * Only the LDS-haloed kernels implement this (v3d_gemm_gn_in_supported says whether a call is one of their shapes); any other call
-     * with gn_in_table set is refused with V3D_ERR_ARG - normalise with v3d_groupnorm_apply first. */
+     * with gn_in_table set is refused with V3D_ERR_ARG - normalise with v3d_groupnorm_apply first.  Since round 4 the operand path always
+     * applies SiLU (every ResBlock half does): a call with gn_in_silu == 0 is not one of the kernels' shapes (v3d_gemm_gn_in_supported = 0). */
     const float* gn_in_table;
     int64_t gn_in_rps;                        /* source rows per table row (S for a 2-D norm, T*S for the 3-D norm) */
     int64_t gn_in_rows;                       /* rows (statistics groups) of the table */
@@ -214,6 +215,10 @@ int v3d_layernorm(const void* x, const float* add, int64_t add_rpg, int64_t add_
  * replaces F.scaled_dot_product_attention / xformers.ops.memory_efficient_attention in
  *   CrossAttention.forward (attention.py:337-341) / MemoryEfficientCrossAttention.forward (attention.py:432-444)
  *   for BasicTransformerBlock.attn1 (attention.py:559-569).
+ * Self-attention only.  The cross-attention of the path (attn2, attention.py:570-574; VideoTransformerBlock.attn2, video_attention.py:126-132)
+ * attends to ONE context token per image in every SVD / V3D config (the CLIP image embedding), where softmax == 1 and the layer reduces to
+ * to_out(to_v(context)): the engine folds it into a per-image vector at pack time (v3d_amd/engine/unet.py asserts context.shape[1] == 1).  The
+ * general N-token form (attention.py:286-349) has no entry point in this library.
  * ---------------------------------------------------------------------------------------------- */
 int v3d_attn_spatial(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vT, void* out,
                      int64_t ldo, int64_t n_img, int64_t S, int32_t heads, float scale, v3d_stream_t stream);

@@ -25,18 +25,14 @@
 
 // Timing experiments (tools/conv_ablate.sh, results in profiles/r03_conv_ablation.txt): -DCONV_ABL=<bits> builds of this file only -
 // compile-time, so the measured loop carries no extra branches.  1 no epilogue, 2 no MFMA, 4 no weight DMA, 4096 no fragment reads,
-// 8192 no halo DMA, 16384 no normalisation chain, 32768 no per-step waits / barrier.  The product build has CONV_ABL = 0.
+// 8192 no halo DMA, 16384 no normalisation chain, 32768 no per-step waits / barrier, 65536 halo source rows folded into an L2-resident window.
+// The product build has CONV_ABL = 0.
 #ifndef CONV_ABL
 #define CONV_ABL 0
 #endif
 #define CABL(bit) ((CONV_ABL & (bit)) != 0)
-// Main-loop placement A/B (compile-time, tools/mainloop_ab.sh): bit 1 = the weight pieces of a step are issued from INSIDE its MFMA sequence
-// (one piece behind MFMA 6 / 15 / 24) instead of behind the fragment reads: the read phase of a wave - which the partner group's MFMA
-// phase has to cover - loses the ~250 cycles its waves spend queueing on the texture-address unit.  bit 2 = no s_setprio around the MFMAs.
-#ifndef CONV_MLV
-#define CONV_MLV 0
-#endif
-#define CMLV(bit) ((CONV_MLV & (bit)) != 0)
+// (round 4 A/B'ed the placement of this loop's pieces - weight DMA inside the MFMA sequence, halo behind the weights, odd waves' DMA in front of
+// their reads, no s_setprio: all neutral or slower, profiles/r04_mainloop_ab.txt; the variants are in profiles/r04_mainloop_variants.patch)
 
 namespace {
 
@@ -53,7 +49,7 @@ struct HaloGeom {
     static constexpr int HBYTES = HPW * 8 * 1024;
     static constexpr int NBUF = HM == HM_CONV ? 2 : 3;                                // halo images in flight
     static constexpr int LA = NBUF - 1;                                               // chunks of look-ahead of the halo loader
-    static constexpr int XF0 = (CMLV(4) && HM == HM_CONV) ? 4 : 3;                                                     // first step (after the issue step) whose MFMA slots carry the transform
+    static constexpr int XF0 = 3;                                                     // first step (after the issue step) whose MFMA slots carry the transform
     static constexpr int XFN = LA * NT - 4;                                           // ... and how many steps do
     static constexpr int NTAB = XF0 >= NT ? 2 : 1;                                    // (scale, shift) slots per wave: 2 when a chunk's chain runs beside the next issue
     static_assert(XFN >= 1, "halo pipeline too shallow");
@@ -452,16 +448,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 constexpr int tap = decltype(tap_)::value;
                 constexpr int dy = HM == HM_CONV ? tap / 3 : tap, dx = HM == HM_CONV ? tap % 3 : 0;
                 constexpr int ltap = (tap + NS - 1) % NT;             // the weight loader's tap, NS-1 steps ahead
-                // (bit 8: the odd waves of a group put their weight pieces IN FRONT of their fragment reads, the even ones behind: two waves queue
-                // on the TA while two read the LDS, then they swap - four waves doing the same thing at once wait ~66 cycles per DMA piece)
-                const int wst_early = rd == 0 ? NS - 1 : rd - 1;
-                const bool early = CMLV(8) && tap != 0 && (wave & 1);
-                if (CMLV(8) && tap != 0) {
-                    if constexpr (ltap == 0) {
-                        if (++w_c == w_c1) set_wtile(++w_it);
-                    }
-                    if (early) issue_w(wst_early, ltap);
-                }
                 // ---- fragment reads of this step
                 if (!CABL(4096)) {
                     const unsigned char* sb = lds + RING_OFF + rd * WSTAGE + wfrag_off;
@@ -485,38 +471,30 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                 }
                 // ---- loaders: the halo image LA chunks ahead (first step of a chunk), then the weights 3 steps ahead
                 if constexpr (tap == G::XF0 % NT) xf_begin();     // (ahead of this step's issue: with NT <= XF0 the chain belongs to the PREVIOUS issue)
-                if constexpr (tap == 0 && !(CMLV(4) && HM == HM_CONV)) issue_halo();
+                if constexpr (tap == 0) issue_halo();
                 if constexpr (ltap == 0) {                            // the weight cursor enters the next chunk
-                    if (!(CMLV(8) && tap != 0)) {
-                        if (++w_c == w_c1) set_wtile(++w_it);
-                    }
+                    if (++w_c == w_c1) set_wtile(++w_it);
                 }
                 const int wst = rd == 0 ? NS - 1 : rd - 1;
-                if (!CMLV(1) && !early) issue_w(wst, ltap);
-                if constexpr (tap == 0 && CMLV(4) && HM == HM_CONV) issue_halo();      // (bit 4: BEHIND this step's weights - the in-order vmcnt then asks for the halo one step later)
+                issue_w(wst, ltap);
                 rd = (rd + 1 == NS) ? 0 : rd + 1;
                 // DMA ops younger than the pieces of the NEXT step's weight stage (issued two steps ago): two weight stages, plus the halo
                 // pieces + table piece when one of the last two issue points was a chunk's first step (they are issued AHEAD of that step's weights)
-                constexpr int HL = (tap == 0 || tap == 1 || (CMLV(4) && HM == HM_CONV && tap == 2)) ? HPW + (XF ? 1 : 0) : 0;
+                constexpr int HL = (tap == 0 || tap == 1) ? HPW + (XF ? 1 : 0) : 0;
                 if (grp == 1 && !CABL(32768)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-                    // (weights issued inside the MFMA sequence: this step's pieces are not out yet - one younger stage instead of two)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((CMLV(1) ? 2 : 2 * 2) + HL) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 + HL) : "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!CMLV(2)) __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(1);
                 // ---- 30 MFMAs, one instruction of the normalisation chain per issue slot
                 constexpr int XSTEP = ((tap - G::XF0) % NT + NT) % NT;    // (3x3: taps 3..7 carry the chain of the image issued at tap 0)
                 constexpr int NOPS = HPW * 4 * 15, NSLOT = G::XFN * 30;
                 static_for<0, MF * NF>([&](auto n_) {
                     constexpr int n = decltype(n_)::value, i = n / NF, j = n % NF;
                     if (!CABL(2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-                    if constexpr (CMLV(1) && (n == 6 || n == 15 || n == 24)) {
-                        issue_w_piece(wst, ltap, (n - 6) / 9);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                     if constexpr (XF && XSTEP >= 0 && XSTEP < G::XFN && !CABL(16384)) {
                         constexpr int s0 = XSTEP * 30 + n;
                         constexpr int o0 = (s0 * NOPS) / NSLOT, o1 = ((s0 + 1) * NOPS) / NSLOT;
@@ -524,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
-                if (!CMLV(2)) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (grp == 0 && !CABL(32768)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (its in-place ds_writes are inline asm)

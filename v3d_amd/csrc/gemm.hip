@@ -34,15 +34,9 @@
 #ifndef V3D_GEMM_TAPINNER_DEFAULT
 #define V3D_GEMM_TAPINNER_DEFAULT 0
 #endif
-// Main-loop placement A/B of the v3 kernels (compile-time, tools/mainloop_ab.sh): bit 1 = the LDS-DMA pieces of a step are issued from INSIDE its
-// MFMA sequence (evenly spaced) instead of behind the fragment reads (see conv.hip CONV_MLV).
-#ifndef GEMM_MLV
-#define GEMM_MLV 0
-#endif
 #ifndef V3D_GEMM_V4_DEFAULT
 #define V3D_GEMM_V4_DEFAULT 0
 #endif
-#define GMLV(bit) ((GEMM_MLV & (bit)) != 0)
 
 namespace {
 
@@ -485,12 +479,6 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     for (int it = 0; it < my_tiles; ++it) {
         for (int kt = 0; kt < nsteps; ++kt, ++s) {
             stamp(s, 0);
-            const bool early = GMLV(8) && (wave & 1);         // (bit 8: odd waves issue their DMA pieces in front of their fragment reads, see conv.hip)
-            if (early) {
-                const int so = __builtin_amdgcn_readfirstlane(ld_k0 * 2);
-#pragma unroll
-                for (int i = 0; i < PPW; ++i) issue_piece(rd == 0 ? NS - 1 : rd - 1, i, so);
-            }
             {
                 const unsigned char* sb = lds + rd * STAGE_BYTES;
 #pragma unroll
@@ -500,11 +488,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
             }
             // refill the ring 3 stages ahead (the buffer of step s-1: its last reader, group 1, finished before B_s) while the
             // fragment reads are in flight
-            const int wst = rd == 0 ? NS - 1 : rd - 1;
-            if (!GMLV(1)) {
-                if (early) issue_advance();
-                else issue(wst);
-            }
+            issue(rd == 0 ? NS - 1 : rd - 1);
             rd = (rd + 1 == NS) ? 0 : rd + 1;
             stamp(s, 1);
             // group 1 must have its fragments in registers before it passes the barrier (the slot is refilled after it);
@@ -515,39 +499,20 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
             }
             stamp(s, 2);
             if (grp == 1) {
-                // own pieces of stage s+1 landed (pieces issued inside the MFMA sequence: this step's are not out yet - one younger stage fewer)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (GMLV(1) ? NS - 3 : NS - 2)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");   // own pieces of stage s+1 landed
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
             stamp(s, 3);
-            if (!V3D_ABL(p, 256) && !GMLV(2)) __builtin_amdgcn_s_setprio(1);
+            if (!V3D_ABL(p, 256)) __builtin_amdgcn_s_setprio(1);
             if (!V3D_ABL(p, 2)) {
-                if constexpr (GMLV(1)) {
-                    const int so = __builtin_amdgcn_readfirstlane(ld_k0 * 2);
-                    static_for<0, MF * NF>([&](auto n_) {
-                        constexpr int n = decltype(n_)::value, i = n / NF, j = n % NF;
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-                        // piece k behind MFMA (k + 1) * 30 / (PPW + 1) - 1
-                        static_for<0, PPW>([&](auto k_) {
-                            constexpr int k = decltype(k_)::value;
-                            if constexpr (n == (k + 1) * (MF * NF) / (PPW + 1) - 1) {
-                                __builtin_amdgcn_sched_barrier(0);
-                                issue_piece(wst, k, so);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        });
-                    });
-                    issue_advance();
-                } else {
-#pragma unroll
-                    for (int i = 0; i < MF; ++i)
-#pragma unroll
-                        for (int j = 0; j < NF; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-                }
             }
-            if (!V3D_ABL(p, 256) && !GMLV(2)) __builtin_amdgcn_s_setprio(0);
+            if (!V3D_ABL(p, 256)) __builtin_amdgcn_s_setprio(0);
             stamp(s, 4);
             __builtin_amdgcn_sched_barrier(0);
             if (grp == 0) {
