@@ -375,11 +375,13 @@ def parity_rollout(device, lat=32):
     out = {"config": f"width 64, T=18, {lat}x{lat} latent, 25 EulerEDM steps, cfg 4.5, decode to {8 * lat}x{8 * lat}", "latent_cosine": round(cos, 6),
            "frames_psnr_db": round(10.0 * math.log10(peak * peak / mse), 2) if mse > 0 else None, "oracle_seconds": round(dt, 1)}
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_parity.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_parity.json")))
         r = rec["rollout_25_steps_width64"]
         out["recorded_64x64"] = {"latent_cosine": r["latent_cosine"], "frames_psnr_db": r["frames_psnr_db"], "decoder_only_psnr_db": r.get("decoder_only_psnr_db"),
-                                 "source": "profiles/r03_parity.json (written by tests/test_headline_parity_gpu.py on the GPU box)",
-                                 "headline_unet_eval": rec.get("headline_unet_eval")}
+                                 "source": "profiles/r04_parity.json (written by tests/test_headline_parity_gpu.py on the GPU box)",
+                                 "headline_unet_eval": rec.get("headline_unet_eval"),
+                                 "headline_midschedule_evals": [rec[k] for k in ("headline_midschedule_eval_step8", "headline_midschedule_eval_step14",
+                                                                                "headline_midschedule_eval_step20") if k in rec]}
     except Exception:
         pass
     return out
