@@ -184,14 +184,19 @@ def _worker8(rank, world, port, q, T):
             out_loc = sharded_unet_eval(net, sh, sh.take_frames(x8, B), None, None, sh.take_frames(ts, B), ctx,
                                         sh.take_frames(y, B), sh.take_frames(ioi.reshape(-1), B))
             out = sh.gather_frames_out(out_loc.contiguous(), B)
+            # the sampler loop with a BATCH of inputs under the uneven 8-way shard (configs[3]: batch of inputs; two here)
+            from v3d_amd import synth
+            NIN = 2
+            noise, c, uc = synth.synthetic_conditioning(T, p["H"], p["W"], seed=11, batch=NIN)
             sampler, den, wr = build_sampler(T, steps=2), build_denoiser(), OpenAIWrapper(net)
-            zs = sharded_sample(sh, sampler, den, wr, lambda zz: zz, noise.clone(), c, uc, B=1)
+            zs = sharded_sample(sh, sampler, den, wr, lambda zz: zz, noise.clone(), c, uc, B=NIN)
             e_unet = e_samp = 0.0
             if rank == 0:      # the unsharded result of the same emulated engine, once
                 full = net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi)
                 e_unet = ((out - full).abs().max() / full.abs().max()).item()
-                extra = {"image_only_indicator": torch.zeros(2, T), "num_video_frames": T}
+                extra = {"image_only_indicator": torch.zeros(2 * NIN, T), "num_video_frames": T}
                 zf = sampler(lambda i, s_, cc: den(wr, i, s_, cc, **extra), noise.clone(), cond=c, uc=uc)
+                assert (zf[:T] - zf[T:]).abs().max() > 1e-3        # the inputs differ
                 e_samp = ((zs - zf).abs().max() / zf.abs().max()).item()
         q.put((rank, sh.T_local, e_unet, e_samp, sh.bytes_sent, sh.counters()))
     except Exception as e:
@@ -219,7 +224,9 @@ def test_eight_ranks_18_frames_is_the_3_3_2_2_2_2_2_2_split_and_matches_unsharde
         assert r[1] >= 0, f"rank {r[0]} failed:\n{r[2]}"
     res.sort()
     assert [r[1] for r in res] == [3, 3, 2, 2, 2, 2, 2, 2]
-    assert res[0][2] <= 5e-5 and res[0][3] <= 5e-5, f"sharded vs unsharded (U-Net, 2-step sampler): {res[0][2:4]}"
+    # (fp32 emulator on both sides: one evaluation agrees to 3e-6; the 2-step guided sampler of the 2-input batch multiplies the summation-order
+    # difference of the 8-way GroupNorm / attention partial sums by the guidance factor: 5.7e-5 measured)
+    assert res[0][2] <= 5e-5 and res[0][3] <= 1.5e-4, f"sharded vs unsharded (U-Net, 2-step sampler): {res[0][2:4]}"
     assert all(r[4] > 0 for r in res)
     # exchange budget: ONE grouped point-to-point call per temporal norm + convolution (halo + statistics) and one per temporal attention:
     # 3 network evaluations here (1 + 2 sampler steps) of a U-Net with 22 VideoResBlocks and 16 transformers -> 3 x (44 + 16) = 180, plus the
