@@ -28,6 +28,36 @@ def _free_port():
     return p
 
 
+def _host_staged_shard_class():
+    """TEST ONLY: FrameShard whose exchanges go through host memory on gloo (two ranks on one device cannot form an RCCL communicator)."""
+    from v3d_amd.dist import FrameShard, _Handle
+
+    class HostStagedFrameShard(FrameShard):
+        def _allreduce_sum(self, t):
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(c)
+
+        def _exchange(self, sends, recvs, async_op=False):
+            torch.cuda.synchronize()
+            ops_ = [dist.P2POp(dist.isend, t.cpu(), self._peer(r), self.group) for t, r in sends]
+            stage = [(t, torch.empty(t.shape, dtype=t.dtype), r) for t, r in recvs]
+            ops_ += [dist.P2POp(dist.irecv, c, self._peer(r), self.group) for _, c, r in stage]
+            self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
+            works = dist.batch_isend_irecv(ops_) if ops_ else []
+
+            def land():
+                for t, c, _ in stage:
+                    t.copy_(c)
+
+            h = _Handle(works, after=land)
+            if not async_op:
+                h.wait()
+            return h
+
+    return HostStagedFrameShard
+
+
 def _worker(rank, world, port, q, T, H, W, steps, inputs=1):
     import sys
     for p_ in (ROOT, os.path.join(ROOT, "tests")):
@@ -46,30 +76,7 @@ def _worker(rank, world, port, q, T, H, W, steps, inputs=1):
         from v3d_amd.engine.vae import run_decoder
         from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
-        class HostStagedFrameShard(FrameShard):
-            """TEST ONLY: gloo on host copies (two ranks on one device cannot form an RCCL communicator)."""
-
-            def _allreduce_sum(self, t):
-                c = t.cpu()
-                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-                t.copy_(c)
-
-            def _exchange(self, sends, recvs, async_op=False):
-                torch.cuda.synchronize()
-                ops_ = [dist.P2POp(dist.isend, t.cpu(), self._peer(r), self.group) for t, r in sends]
-                stage = [(t, torch.empty(t.shape, dtype=t.dtype), r) for t, r in recvs]
-                ops_ += [dist.P2POp(dist.irecv, c, self._peer(r), self.group) for _, c, r in stage]
-                self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
-                works = dist.batch_isend_irecv(ops_) if ops_ else []
-
-                def land():
-                    for t, c, _ in stage:
-                        t.copy_(c)
-
-                h = _Handle(works, after=land)
-                if not async_op:
-                    h.wait()
-                return h
+        HostStagedFrameShard = _host_staged_shard_class()
 
         assert ops.get_ops().name == "hip"
         dev = "cuda"
@@ -161,28 +168,7 @@ def _worker_cfg2(rank, world, port, q):
         from v3d_amd.dist import FrameShard, _Handle, sharded_unet_eval
         from v3d_amd.sgm.modules.diffusionmodules.video_model import VideoUNet
 
-        class HostStagedFrameShard(FrameShard):
-            def _allreduce_sum(self, t):
-                c = t.cpu()
-                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-                t.copy_(c)
-
-            def _exchange(self, sends, recvs, async_op=False):
-                torch.cuda.synchronize()
-                ops_ = [dist.P2POp(dist.isend, t.cpu(), self._peer(r), self.group) for t, r in sends]
-                stage = [(t, torch.empty(t.shape, dtype=t.dtype), r) for t, r in recvs]
-                ops_ += [dist.P2POp(dist.irecv, c, self._peer(r), self.group) for _, c, r in stage]
-                self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
-                works = dist.batch_isend_irecv(ops_) if ops_ else []
-
-                def land():
-                    for t, c, _ in stage:
-                        t.copy_(c)
-
-                h = _Handle(works, after=land)
-                if not async_op:
-                    h.wait()
-                return h
+        HostStagedFrameShard = _host_staged_shard_class()
 
         assert ops.get_ops().name == "hip"
         dev = "cuda"
