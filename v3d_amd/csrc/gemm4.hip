@@ -6,8 +6,6 @@
 // at issue; the matrix pipes are busy 41-50 %.  The read phase is not hidden by anything inside the wave itself, the per-step barrier ties
 // eight waves together, and every piece of work that is not an MFMA (LDS-DMA issue: ~66 cycles per piece with four waves queueing on the TA)
 // lengthens a phase the partner has to match.
-// RESULT (profiles/r04_mainloop_ab.txt section 3): bit-equal to v3 and 5 % SLOWER at 4096^3 - inside one wave nothing overlaps an MFMA (a
-// ds_read_b128 between two MFMAs costs its wave 10-17 cycles, an LDS-DMA piece 20-50); kept as the measured alternative, off by default.
 // Here a block has four waves, each alone on its SIMD with the whole 512-register file:
 //   * wave tile 96 x 160 (192 x 320 block tile, the N = 320 k family) or 128 x 128 (256 x 256): 16 fragment reads feed 60 / 64 MFMAs
 //     (v3: 11 / 12 reads per 30 / 32) - a quarter less LDS traffic per flop;
