@@ -22,14 +22,14 @@ typedef __amdgpu_buffer_rsrc_t bufrsrc_t;
         }                                                                      \
     } while (0)
 
-constexpr int NW = 8;
+constexpr int NW = 8;      // (wave slots of the LDS ring / row assignment; blocks of 4 waves use half of them)
 
 // RPP = rows per piece (16 / 8 / 4 / 1); bytes per row and piece = 1024 / RPP.  A wave owns RG = 2 groups of RPP rows and walks their k
 // (address arithmetic per piece: one scalar add - the first version divided per piece and measured its own VALU, 20.0 B/clk for everything)
 constexpr int RG = 2;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int RPP, int DEPTH, bool REG>
-__global__ __launch_bounds__(512, 2) void dma_rate_kernel(const char* src, unsigned bytes, unsigned stride, int shared, int total, unsigned long long* out, int rot) {
+template <int RPP, int DEPTH, bool REG, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, 2) void dma_rate_kernel(const char* src, unsigned bytes, unsigned stride, int shared, int total, unsigned long long* out, int rot) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NW * DEPTH * 1024];
     static_assert(DEPTH % RG == 0, "");
     const int lane = threadIdx.x & 63;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void dma_rate_kernel(const char* src, unsig
     if (total < 0) out[0] = lds[threadIdx.x];
 }
 
-template <int RPP, int DEPTH, bool REG = false>
+template <int RPP, int DEPTH, bool REG = false, int WAVES = 8>
 void run(const char* what, const char* src, size_t bytes, unsigned stride, int shared, int laps, int ncu, unsigned long long* dout, int rot = 0, int grid = 0) {
     if (!grid) grid = ncu;
     hipEvent_t e0, e1;
@@ -88,17 +88,17 @@ void run(const char* what, const char* src, size_t bytes, unsigned stride, int s
     const int total = ksteps * RG;               // pieces per wave
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((dma_rate_kernel<RPP, DEPTH, REG>), dim3(grid), dim3(512), 0, 0, src, (unsigned)bytes, stride, shared, total, dout, rot);
+        hipLaunchKernelGGL((dma_rate_kernel<RPP, DEPTH, REG, WAVES>), dim3(grid), dim3(64 * WAVES), 0, 0, src, (unsigned)bytes, stride, shared, total, dout, rot);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    const double per_cu = (double)total * NW * 1024.0;     // bytes one CU moved
-    printf("%-30s %s %2d rows x %4d B  depth %2d  blocks %3d  rows/block %3d  %8.1f us  %6.2f TB/s aggregate  %5.1f B/clk/CU (2.4 GHz)\n", what,
-           REG ? "VGPR+ds_write" : "LDS-DMA      ", RPP, 1024 / RPP, DEPTH, grid, NW * RG * RPP, best * 1e3, per_cu * grid / (best * 1e-3) / 1e12,
-           per_cu / (best * 1e-3 * 2.4e9));
+    const double per_cu = (double)total * WAVES * 1024.0;     // bytes one block moved
+    printf("%-30s %s %2d rows x %4d B  depth %2d  blocks %3d x %d waves  rows/block %3d  %8.1f us  %6.2f TB/s aggregate  %5.1f B/clk/CU (2.4 GHz)\n", what,
+           REG ? "VGPR+ds_write" : "LDS-DMA      ", RPP, 1024 / RPP, DEPTH, grid, WAVES, NW * RG * RPP, best * 1e3, per_cu * grid / (best * 1e-3) / 1e12,
+           per_cu * grid / ncu / (best * 1e-3 * 2.4e9));
 }
 
 int main(int argc, char** argv) {
@@ -139,5 +139,12 @@ int main(int argc, char** argv) {
     run<16, 8>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout, 0, 64);
     run<16, 8>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout, 0, 8);
     run<16, 8, true>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout, 0, 8);
+    printf("-- how the rate scales with the waves that issue (B/clk per CU; 512 blocks = two 8-wave blocks per CU)\n");
+    run<16, 8, false, 4>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout);
+    run<8, 8, false, 4>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout);
+    run<16, 16, false, 4>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout);
+    run<16, 8, false, 8>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout, 0, 2 * ncu);
+    run<8, 8, false, 8>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout, 0, 2 * ncu);
+    run<16, 8, false, 4>("shared rows, 16 laps", src, bytes, stride, 1, 16, ncu, dout, 0, 64);
     return 0;
 }
