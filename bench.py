@@ -399,6 +399,7 @@ def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
     from v3d_amd.ops import get_ops
     from v3d_amd.sgm.modules.diffusionmodules.sampling import EulerEDMSampler
     N = args.shard_sim
+    B_IN, E_STEPS = args.inputs, args.edm_steps          # (BASELINE.json configs[3]: --inputs 4 --edm-steps 50)
     ops = get_ops()
     cus = ops.cu_count
 
@@ -416,35 +417,16 @@ def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
 
-    def fill_of(g):
-        """Fraction of the CU slots the launch keeps busy over its rounds, mirroring the dispatch of v3d_amd/csrc/gemm.hip: persistent 192 x 320 /
-        256 x 256 tiles (one block per CU; the haloed convolutions share their last round out, stream-K) where they fill the chip about as well
-        as the 128 x 128 / 128 x 64 tiles of the two-blocks-per-CU kernels, else those."""
-        cdiv = lambda a, b: -(-a // b)
-        if g.gn_in is not None:
-            return 1.0 if cdiv(g.M, 192) * cdiv(g.N, 320) >= cus // 2 else cdiv(g.M, 192) * cdiv(g.N, 320) / cus
-        if g.geglu and cdiv(g.M, 256) * cdiv(g.N, 128) >= 2 * cus:
-            nt = cdiv(g.M, 256) * cdiv(g.N, 128)
-            return nt / (cdiv(nt, 2 * cus) * 2 * cus)
-        bm, bn = (192, 320) if (g.N % 320 == 0 and not g.geglu) else (256, 256)
-        nt3 = cdiv(g.M, bm) * cdiv(g.N, bn)
-        fill3 = nt3 / (cdiv(nt3, cus) * cus) * (g.N / (cdiv(g.N, bn) * bn))
-        w128, w64 = cdiv(g.N, 128) * 128, cdiv(g.N, 64) * 64
-        wv2 = min(w64, w128)
-        nt2 = cdiv(g.M, 128) * (wv2 // (64 if w64 < w128 else 128)) * max(1, g.batch)
-        fill2 = nt2 / (cdiv(nt2, 2 * cus) * 2 * cus) * (g.N / wv2)
-        return fill3 if (fill3 >= 0.9 * fill2 and g.batch == 1 and g.N >= 256 and g.K % 32 == 0) else fill2
-
     def run(rank):
         sh = SimFrameShard(T_FRAMES, N, rank) if N > 1 else None
         s2, s6 = sampler_of(2), sampler_of(6)
-        extra = {"image_only_indicator": torch.zeros(2, T_FRAMES, device=device), "num_video_frames": T_FRAMES}
+        extra = {"image_only_indicator": torch.zeros(2 * B_IN, T_FRAMES, device=device), "num_video_frames": T_FRAMES}
 
         def sample(smp):
             if sh is None:
-                z = smp(lambda i, sg, cc: denoiser(wrapped, i, sg, cc, **extra), noise.clone(), cond=c, uc=uc)
-                return dec(z * (1.0 / 0.18215), timesteps=T_FRAMES)
-            return sharded_sample(sh, smp, denoiser, wrapped, lambda z: dec(z * (1.0 / 0.18215), timesteps=sh.T_local), noise.clone(), c, uc, B=1, gather=False)
+                z = smp(lambda i, sg, cc: denoiser(wrapped, i, sg, cc, **extra), noise.clone(), cond=c, uc=uc) * (1.0 / 0.18215)
+                return torch.cat([dec(z[i:i + T_FRAMES], timesteps=T_FRAMES) for i in range(0, z.shape[0], T_FRAMES)], dim=0)      # (as make_step: one input at a time)
+            return sharded_sample(sh, smp, denoiser, wrapped, lambda z: dec(z * (1.0 / 0.18215), timesteps=sh.T_local), noise.clone(), c, uc, B=B_IN, gather=False)
 
         t2, t6 = wall(lambda: sample(s2)), wall(lambda: sample(s6))
         ev = (t6 - t2) / 4.0
@@ -458,7 +440,7 @@ def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
             e0.record()
             r = orig(g)
             e1.record()
-            rec.append((fill_of(g), e0, e1))
+            rec.append((ops.last_gemm_launch()["fill"], e0, e1))          # the library's own record of what it launched (tiles / CU slots)
             return r
         ops.gemm = timed_gemm
         b0, x0 = (sh.bytes_sent, sh.n_exchanges) if sh else (0, 0)
@@ -471,7 +453,7 @@ def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
         under = [ms for f, ms in ((f, a.elapsed_time(b)) for f, a, b in rec) if f < 0.75]
         half = [ms for f, ms in ((f, a.elapsed_time(b)) for f, a, b in rec) if f < 0.5]
         out = {"frames": sh.T_local if sh else T_FRAMES, "ms_per_unet_eval": round(ev, 2), "ms_per_decode": round(decode, 2),
-               "ms_per_sample_25_steps_compute_only": round(STEPS * ev + decode, 1),
+               "ms_per_sample_compute_only": round(E_STEPS * ev + decode, 1), "edm_steps": E_STEPS, "inputs": B_IN,
                "gemm_launches_per_2_step_sample": len(rec), "launches_filling_under_75pct_of_the_cu_slots": len(under), "their_share_of_gemm_time": round(sum(under) / max(tot, 1e-9), 3),
                "launches_filling_under_50pct": len(half), "their_share_of_gemm_time_50pct": round(sum(half) / max(tot, 1e-9), 3)}
         if sh:
@@ -490,10 +472,10 @@ def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
     if N == 1:
         return {"unsharded": base}
     r_first, r_last = run(0), run(N - 1)
-    slow = max(r_first["ms_per_sample_25_steps_compute_only"], r_last["ms_per_sample_25_steps_compute_only"])
+    slow = max(r_first["ms_per_sample_compute_only"], r_last["ms_per_sample_compute_only"])
     return {"world": N, "cus": cus, "unsharded": base, "rank_0": r_first, f"rank_{N - 1}": r_last,
             "ideal_speedup_most_loaded_rank": round(T_FRAMES / r_first["frames"], 2),
-            "compute_only_strong_scaling_ceiling": round(base["ms_per_sample_25_steps_compute_only"] / slow, 2),
+            "compute_only_strong_scaling_ceiling": round(base["ms_per_sample_compute_only"] / slow, 2),
             "note": "compute of one rank on one GPU with self-fed halos / K|V / statistics (v3d_amd/dist.py SimFrameShard); communication is NOT timed - "
                     "no RCCL run of this path exists (one GPU per build box)"}
 
@@ -567,12 +549,12 @@ def main():
     # replica mode: every rank generates its own sample (different seed per rank); frame-shard mode: ONE sample, same inputs everywhere
     noise, c, uc = synth.synthetic_conditioning(T_FR, LH, LW, seed=23 + (0 if shard_mode else rank), device=device, batch=B_IN)
     if args.shard_sim:
-        if world > 1 or scene or B_IN != 1:
-            raise SystemExit("--shard-sim runs on one GPU, headline shapes, one input")
+        if world > 1 or scene:
+            raise SystemExit("--shard-sim runs on one GPU at the headline shapes (--inputs / --edm-steps select BASELINE.json configs[3]'s batch of inputs)")
         res = shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc)
         print(json.dumps({"metric": f"frame-shard compute simulation, V3D_512 18-frame sample over {args.shard_sim} GPUs (one GPU measured)", "n_gpus": 1,
                           "dtype": "bf16", "data": "synthetic", "config": {"workload": "BASELINE.json configs[2]/[3] sub-problem of one rank: V3D_512, 18 frames "
-                          f"sharded over {args.shard_sim} ranks, 64x64 latents, guided batch of 2, 18-frame decode"}, "shard_sim": res}), flush=True)
+                          f"sharded over {args.shard_sim} ranks, 64x64 latents, {B_IN} input(s) = guided batch of {2 * B_IN}, {E_STEPS} EulerEDM steps, 18-frame decode"}, "shard_sim": res}), flush=True)
         return
     shard = None
     if world > 1:

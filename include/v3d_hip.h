@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 4
+#define V3D_ABI_VERSION 5
 
 typedef void* v3d_stream_t; /* hipStream_t */
 
@@ -186,6 +186,13 @@ int v3d_sizeof_gemm_args(void);
  * ---------------------------------------------------------------------------------------------- */
 int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots,
                         int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, v3d_stream_t stream);
+/* ABI 5: statistics AND table in one launch - v3d_groupnorm_stats whose LAST block of each statistics group to finish runs the fold of
+ * v3d_groupnorm_finalize on the group's slots (same fp64 fixed-order sums, so the table is bit-reproducible whichever block is last):
+ * the launch-bound finalize kernel behind every stand-alone statistics pass disappears (41 per U-Net evaluation).  tickets: [n_img /
+ * imgs_per_stat] uint32, ZERO on entry, left zero.  groups even and <= 32.  Same reference call sites as the three-step form. */
+int v3d_groupnorm_stats_table(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots, uint32_t* tickets,
+                              int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, const float* gamma, const float* beta,
+                              double count, float eps, float* table, v3d_stream_t stream);
 int v3d_groupnorm_finalize(const float* stats, int64_t nslots, double* sums, int64_t n_stat, int32_t groups,
                            const float* gamma, const float* beta, int64_t C, double count, float eps, float* table,
                            v3d_stream_t stream);

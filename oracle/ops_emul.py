@@ -138,6 +138,11 @@ class EmulOps(OpsBase):
         stats[:, 0, :, 0] += xg.sum(dim=(1, 3))          # [stat group][slot][group][2]; the emulator uses slot 0 only
         stats[:, 0, :, 1] += (xg * xg).sum(dim=(1, 3))
 
+    def groupnorm_stats_table(self, x1, x2, stats, tickets, n_img, S, groups, imgs_per_stat, gamma, beta, count, eps, table):
+        """v3d_groupnorm_stats_table (ABI 5): statistics + table in one launch == stats, then finalize."""
+        self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
+        self.groupnorm_finalize(stats, None, gamma, beta, count, eps, table)
+
     def groupnorm_finalize(self, stats, sums, gamma, beta, count, eps, table):
         if stats is not None:
             tot = stats.double().sum(dim=1)              # [n_stat, groups, 2]

@@ -1,3 +1,4 @@
+import contextlib
 import os
 import sys
 
@@ -24,6 +25,49 @@ def hip_ops():
     """The product backend; fails loudly (no skip) when the extension or the GPU is missing on a -m gpu run."""
     from v3d_amd.hip import HipOps
     return HipOps()
+
+
+# ---- the fp32 oracle executed on the GPU ---------------------------------------------------------------------------------------------
+# oracle/sgm_oracle.py is a pure functional torch restatement: given tensors on a device it runs there.  The full-width (-m gpu) parity
+# tests hand it cuda tensors, so the CHECKER runs as fp32 ATen kernels on the GPU (rocBLAS fp32 GEMMs, the native im2col convolutions -
+# MIOpen is switched off: this image carries no gfx950 find-db and every first convolution would JIT-compile -, the math SDPA backend,
+# TF32 off) instead of ~15 minutes of CPU time per suite run (GPUTEST_r04: the driver's 1200 s limit hit after 144 of 168 tests, ~900 s of
+# them the CPU oracle).  The device-executed oracle is itself pinned: tests/test_headline_parity_gpu.py::test_device_oracle_is_pinned holds
+# it to the reference-generated fixtures (tests/golden/v3d_tiny.pt) and to the CPU-executed oracle at rtol 1e-4.
+# V3D_ORACLE_DEVICE=cpu restores the CPU-executed checker everywhere.
+ORACLE_DEVICE = os.environ.get("V3D_ORACLE_DEVICE", "cuda")
+
+
+@contextlib.contextmanager
+def device_oracle():
+    """with device_oracle() as dev: ref = O.unet_forward(odev(sd, dev), cfg, *odev(inputs, dev)).cpu()"""
+    if ORACLE_DEVICE == "cpu":
+        yield "cpu"
+        return
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    old_mm, old_cd = torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.allow_tf32
+    old_prec = torch.get_float32_matmul_precision()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    torch.set_float32_matmul_precision("highest")
+    try:
+        with torch.backends.cudnn.flags(enabled=False), sdpa_kernel(SDPBackend.MATH):
+            yield ORACLE_DEVICE
+    finally:
+        torch.backends.cuda.matmul.allow_tf32, torch.backends.cudnn.allow_tf32 = old_mm, old_cd
+        torch.set_float32_matmul_precision(old_prec)
+        torch.cuda.empty_cache()
+
+
+def odev(obj, dev):
+    """Tensors (also inside dicts / lists / tuples) as fp32 on the oracle's device; everything else unchanged."""
+    if torch.is_tensor(obj):
+        return obj.detach().to(device=dev, dtype=torch.float32) if obj.is_floating_point() else obj.detach().to(dev)
+    if isinstance(obj, dict):
+        return {k: odev(v, dev) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(odev(v, dev) for v in obj)
+    return obj
 
 
 def rel_cos(a: torch.Tensor, b: torch.Tensor):

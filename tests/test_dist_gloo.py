@@ -198,7 +198,16 @@ def _worker8(rank, world, port, q, T):
                 zf = sampler(lambda i, s_, cc: den(wr, i, s_, cc, **extra), noise.clone(), cond=c, uc=uc)
                 assert (zf[:T] - zf[T:]).abs().max() > 1e-3        # the inputs differ
                 e_samp = ((zs - zf).abs().max() / zf.abs().max()).item()
-        q.put((rank, sh.T_local, e_unet, e_samp, sh.bytes_sent, sh.counters()))
+            cnt = dict(sh.counters())
+            # ... and the single-input sampler loop at its own, tighter bound (the 1.5e-4 above belongs to the 2-input batch only)
+            noise1, c1, uc1, *_ = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])          # (the inputs this bound was set on in round 3)
+            zs1 = sharded_sample(sh, sampler, den, wr, lambda zz: zz, noise1.clone(), c1, uc1, B=1)
+            cnt["e_samp_b1"] = 0.0
+            if rank == 0:
+                extra1 = {"image_only_indicator": torch.zeros(2, T), "num_video_frames": T}
+                zf1 = sampler(lambda i, s_, cc: den(wr, i, s_, cc, **extra1), noise1.clone(), cond=c1, uc=uc1)
+                cnt["e_samp_b1"] = ((zs1 - zf1).abs().max() / zf1.abs().max()).item()
+        q.put((rank, sh.T_local, e_unet, e_samp, sh.bytes_sent, cnt))
     except Exception as e:
         import traceback
         q.put((rank, -1, traceback.format_exc(), str(e), 0, {}))
@@ -227,6 +236,7 @@ def test_eight_ranks_18_frames_is_the_3_3_2_2_2_2_2_2_split_and_matches_unsharde
     # (fp32 emulator on both sides: one evaluation agrees to 3e-6; the 2-step guided sampler of the 2-input batch multiplies the summation-order
     # difference of the 8-way GroupNorm / attention partial sums by the guidance factor: 5.7e-5 measured)
     assert res[0][2] <= 5e-5 and res[0][3] <= 1.5e-4, f"sharded vs unsharded (U-Net, 2-step sampler): {res[0][2:4]}"
+    assert res[0][5]["e_samp_b1"] <= 5e-5, f"sharded vs unsharded 2-step sampler, ONE input: {res[0][5]['e_samp_b1']}"
     assert all(r[4] > 0 for r in res)
     # exchange budget: ONE grouped point-to-point call per temporal norm + convolution (halo + statistics) and one per temporal attention:
     # 3 network evaluations here (1 + 2 sampler steps) of a U-Net with 22 VideoResBlocks and 16 transformers -> 3 x (44 + 16) = 180, plus the

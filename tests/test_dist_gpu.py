@@ -4,10 +4,12 @@ the product path: HipOps backend, split-halo CONVT3 GEMM (tmin = -1 / tmax = T_l
 on the gathered K|V, all-reduced GroupNorm partial sums with the global count, global frame-position ids, per-rank guidance scale.
 
 sharded == unsharded HIP result for a U-Net evaluation, a VAE decode and the whole sharded sampler loop (`sharded_sample`), for the
-uneven split 3 = 2 + 1 and for 18 = 9 + 9 (BASELINE.json configs[2]) at reduced width.  Tolerance: the two runs execute the same
-kernels on different work decompositions (tile counts, accumulation order), so they agree to bf16 rounding noise - the bound of the
-one-evaluation bound (max rel 4e-2, cosine >= 0.999): two identical eager runs of the tiny network already differ by 1-2e-2 max rel
-(GroupNorm partial sums meet in fp32 atomics whose order varies, one bf16 ulp of a normalised activation then walks through 50 layers)."""
+uneven split 3 = 2 + 1 and for 18 = 9 + 9 (BASELINE.json configs[2]) at reduced width.  Tolerance: the engine has been bit-reproducible
+since round 3 (no floating-point atomics: GroupNorm partial sums are written one slot per writer and added in a fixed order in fp64), so the
+two runs differ ONLY through the other work decomposition - other tile counts, the 3-D GroupNorm sums grouped per rank, the K|V rows of the
+temporal attention in gathered order - i.e. by bf16 rounding of single activations that then walks through ~50 layers.  Measured (round 4
+logs, gpurun_out/dist_gpu_T*.log): U-Net max rel 1.4e-2..1.9e-2 (2.1e-2 with two inputs) at cosine >= 0.99984, decode <= 1.2e-2 at cosine
+0.99996 (bit-equal for the 2 + 1 split); the bounds below sit just above those numbers - max rel half of the 4e-2 bf16-vs-fp32 bar, cosine 0.9998."""
 import os
 import socket
 
@@ -142,8 +144,8 @@ def test_two_ranks_on_one_gpu_hip_sharded_equals_unsharded(T, H, W, steps, split
         # (deterministic kernels since round 3: what is left is the other work decomposition - partial sums of the 3-D GroupNorm grouped per
         # rank, other tile counts - i.e. rounding; rounds 1-2 could only bound this at the 4e-2 of a bf16-vs-fp32 comparison)
         # (2-input case: 2.1e-2 measured - four samples per evaluation, other tile boundaries; still inside the 4e-2 one-evaluation bar)
-        assert r_unet[0] <= (3e-2 if inputs > 1 else 2e-2) and r_unet[1] >= 0.9995, f"rank {rank}: sharded U-Net vs unsharded HIP: {r_unet}"
-        assert r_dec[0] <= 2e-2 and r_dec[1] >= 0.9995, f"rank {rank}: sharded decode vs unsharded HIP: {r_dec}"
+        assert r_unet[0] <= (3e-2 if inputs > 1 else 2e-2) and r_unet[1] >= 0.9998, f"rank {rank}: sharded U-Net vs unsharded HIP: {r_unet}"
+        assert r_dec[0] <= 1.5e-2 and r_dec[1] >= 0.9999, f"rank {rank}: sharded decode vs unsharded HIP: {r_dec}"
         assert r_samp[1] >= 0.995, f"rank {rank}: sharded sampler loop vs unsharded HIP: {r_samp}"
         assert sent > 0
 
@@ -187,10 +189,11 @@ def _worker_cfg2(rank, world, port, q):
         out = sh.gather_frames_out(out_loc.float().contiguous(), B).cpu()
         res = None
         if rank == 0:
+            from conftest import device_oracle, odev
             from oracle import sgm_oracle as O
-            sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
             t0 = time.time()
-            ref = O.unet_forward(sd, synth.unet_config(320), x8, ts, ctx, y, T, ioi)
+            with device_oracle() as od:              # the fp32 oracle as ATen kernels on the GPU (conftest.device_oracle)
+                ref = O.unet_forward(odev(net.state_dict(), od), synth.unet_config(320), *odev((x8, ts, ctx, y), od), T, ioi.to(od)).cpu()
             res = rel_cos(out, ref) + (round(time.time() - t0, 1),)
         dist.barrier()
         q.put((rank, sh.T_local, res, sh.bytes_sent))

@@ -1,12 +1,12 @@
 """-m gpu: the product path end to end on the HIP kernels (default backend — nothing injected) against
- (a) the reference-generated fixtures tests/golden/v3d_tiny.pt and (b) the fp32 CPU oracle on fresh seeded inputs.
+ (a) the reference-generated fixtures tests/golden/v3d_tiny.pt and (b) the fp32 oracle (executed on the GPU in fp32: conftest.device_oracle) on fresh seeded inputs.
 Tolerance: bf16 kernels vs fp32 reference: cosine >= 0.999 and max|err|/max|ref| <= 4e-2 for a full
 network evaluation (per-op bound 2e-2 is enforced in test_ops_gpu.py); sampler latents: cosine >= 0.99."""
 import pytest
 from conftest import record_parity
 import torch
 
-from conftest import rel_cos, full_inputs as _full_inputs  # noqa: F401  (`full_unet` is the session fixture of conftest.py)
+from conftest import device_oracle, odev, rel_cos, full_inputs as _full_inputs  # noqa: F401  (`full_unet` is the session fixture of conftest.py)
 from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs, to_dev
 from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
@@ -75,8 +75,8 @@ def test_unet_vs_oracle_other_shapes(T, H, W, B2):
     y = torch.randn(n, 768, generator=g)
     ioi = torch.zeros(B2, T)
     net = build_unet(DEV)
-    sd = {k: v.float().cpu() for k, v in net.state_dict().items()}
-    ref = O.unet_forward(sd, synth.unet_config(TINY["model_channels"]), x8, ts, ctx, y, T, ioi)
+    with device_oracle() as od:
+        ref = O.unet_forward(odev(net.state_dict(), od), synth.unet_config(TINY["model_channels"]), *odev((x8, ts, ctx, y), od), T, ioi.to(od)).cpu()
     out = net(x8.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi.to(DEV))
     rel, cos = rel_cos(out, ref)
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
@@ -97,11 +97,8 @@ def test_scene_shape_vs_oracle():
     ioi = torch.zeros(2, T)
     net = build_unet(DEV)
     out = net(x8.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi.to(DEV)).float().cpu()
-    sd = {k: v.float().cpu() for k, v in net.state_dict().items()}
-    nthr = torch.get_num_threads()
-    torch.set_num_threads(min(nthr, 32))
-    ref = O.unet_forward(sd, synth.unet_config(TINY["model_channels"]), x8, ts, ctx, y, T, ioi)
-    torch.set_num_threads(nthr)
+    with device_oracle() as od:
+        ref = O.unet_forward(odev(net.state_dict(), od), synth.unet_config(TINY["model_channels"]), *odev((x8, ts, ctx, y), od), T, ioi.to(od)).cpu()
     rel, cos = rel_cos(out, ref)
     record_parity("scene_shape_unet_eval_width64", {"T": T, "latent": [H, W], "images": n, "max_rel_err": round(rel, 5), "cosine": round(cos, 6)})
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
@@ -165,19 +162,19 @@ def test_scene_config_batch_independence(full_unet):
 
 
 def test_full_width_vs_oracle(full_unet):
-    """Full-width network (320 channels, 64 x 64 latents) against the fp32 CPU oracle on a 2-image batch (1 frame, cfg 2)."""
+    """Full-width network (320 channels, 64 x 64 latents) against the fp32 oracle on a 2-image batch (1 frame, cfg 2)."""
     from oracle import sgm_oracle as O
     from v3d_amd import synth
     x, ts, ctx, y = _full_inputs(2, 11)
-    sd = {k: v.detach().float().cpu() for k, v in full_unet.state_dict().items()}
-    ref = O.unet_forward(sd, synth.unet_config(320), x, ts, ctx, y, 1, torch.zeros(2, 1))
+    with device_oracle() as od:
+        ref = O.unet_forward(odev(full_unet.state_dict(), od), synth.unet_config(320), *odev((x, ts, ctx, y), od), 1, torch.zeros(2, 1, device=od)).cpu()
     out = full_unet(x.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=1, image_only_indicator=torch.zeros(2, 1, device=DEV))
     rel, cos = rel_cos(out, ref)
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
 
 
 def test_full_width_decoder_vs_oracle():
-    """Full-width VideoDecoder (128 base channels, 64 x 64 latent -> 512 x 512) against the fp32 CPU oracle on one frame."""
+    """Full-width VideoDecoder (128 base channels, 64 x 64 latent -> 512 x 512) against the fp32 oracle on one frame."""
     from oracle import sgm_oracle as O
     from v3d_amd import synth
     from v3d_amd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
@@ -185,8 +182,8 @@ def test_full_width_decoder_vs_oracle():
         dec = VideoDecoder(**synth.decoder_config(128)).eval()
     synth.init_module_fast(dec, seed=2)
     z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5))
-    sd = {k: v.detach().float().cpu() for k, v in dec.state_dict().items()}
-    ref = O.decoder_forward(sd, synth.decoder_config(128), z, 1)
+    with device_oracle() as od:
+        ref = O.decoder_forward(odev(dec.state_dict(), od), synth.decoder_config(128), odev(z, od), 1).cpu()
     out = dec(z.to(DEV), timesteps=1)
     assert out.shape == (1, 3, 512, 512)
     rel, cos = rel_cos(out, ref)

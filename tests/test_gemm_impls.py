@@ -11,8 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl,extra", [("1", {}), ("2", {}), ("3", {}), ("2", {"V3D_GEMM_SPLITK": "3"}), ("3", {"V3D_GEMM_V3S": "0"}),
-                                        ("3", {"V3D_GEMM_V4": "1"})])       # (the opt-in one-wave-per-SIMD kernels of gemm4.hip take every launch they can)
+@pytest.mark.parametrize("impl,extra", [("1", {}), ("2", {}), ("3", {}), ("2", {"V3D_GEMM_SPLITK": "3"}), ("3", {"V3D_GEMM_V3S": "0"})])
 def test_gemm_parity_with_forced_impl(impl, extra):
     env = dict(os.environ, V3D_GEMM_IMPL=impl, **extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_sweep.py"), "--check", "--only=__none__"],

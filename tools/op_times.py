@@ -17,7 +17,12 @@ def wrap(name, keyfn):
     def f(*a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); r = orig(*a, **k); e1.record()
-        rec.append((keyfn(*a, **k), e0, e1))
+        key = keyfn(*a, **k)
+        if name == "gemm":       # + the library's own record of the kernel that took the launch (family, tile, tiles, fill)
+            li = ops.last_gemm_launch()
+            fam = {1: "v1", 2: "v2", 3: "v3", 5: "halo"}.get(li["family"], "?") + (f"/sk{li['splitk']}" if li["splitk"] > 1 else "") + ("/tail" if li["streamk_tail"] else "")
+            key = (key[0] + f"  <{fam} {li['bm']}x{li['bn']} tiles={li['tiles']} x{li['blocks_per_cu']}/CU fill={li['fill']:.2f}>", key[1])
+        rec.append((key, e0, e1))
         return r
     setattr(ops, name, f)
 def gk(g):
@@ -49,3 +54,11 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:400]:
     tf = f"{v[2] / v[1] / 1e9:7.0f} TF/s" if v[2] else ""
     print(f"{v[1]:8.3f} ms {v[1] / tot * 100:5.1f}% n={v[0]:3d} avg={v[1] / v[0] * 1e3:8.1f}us {tf}  {k}")
 print(f"total {tot:.2f} ms over {len(rec)} launches")
+# GEMM-family time by kernel family (what the dispatcher of gemm.hip sent where)
+fam = collections.OrderedDict()
+for k, v in agg.items():
+    if k.startswith("gemm "):
+        f = k[k.index("<") + 1:].split()[0]
+        d = fam.setdefault(f, [0, 0.0, 0.0]); d[0] += v[0]; d[1] += v[1]; d[2] += v[2]
+for f, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+    print(f"family {f:10s} {v[1]:8.3f} ms  n={v[0]:4d}  {v[2] / v[1] / 1e9:7.0f} TF/s")

@@ -31,8 +31,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build the gfx950 kernels)")
 
 
-def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+LAB = os.path.join(os.path.dirname(HERE), "tools", "lab")     # lab-only kernels (round-4 gemm4.hip): linked into the experiments library only
+
+
+def sources(experiments: bool = False):
+    src = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    if experiments and os.path.isdir(LAB):
+        src += sorted(os.path.join(LAB, f) for f in os.listdir(LAB) if f.endswith(".hip"))
+    return src
 
 
 def _stale(out: str, deps) -> bool:
@@ -58,7 +64,7 @@ def _build(force, verbose, LIBDIR, libname, extra) -> str:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "v3d_hip.h"))
     objs, jobs = [], []
-    for src in sources():
+    for src in sources(experiments=bool(extra)):
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
@@ -66,7 +72,7 @@ def _build(force, verbose, LIBDIR, libname, extra) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, *extra, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, *FILE_FLAGS.get(os.path.basename(src), []), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print("[v3d_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

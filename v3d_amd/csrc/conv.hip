@@ -628,6 +628,7 @@ static int conv_halo_launch_t(const V3dGemmParams& p0, hipStream_t st) {
     // (18 / 6 steps) of idling removed)
     const int grid = v3d_sk_plan(p, ntiles, (int)(p.K / 32), 4, 2, (size_t)192 * 320 * 4, (void*)st);
     const bool xf = p.gn_in != nullptr, gn = p.gn_stats != nullptr;
+    v3d_note_launch(5, 192, 320, ntiles, 1, p.sk_tail);
     if (xf && gn) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
     else if (xf) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, true, false>), dim3(grid), dim3(512), 0, st, p, ntiles);
     else if (gn) hipLaunchKernelGGL((conv_halo_kernel<HM, W_, false, true>), dim3(grid), dim3(512), 0, st, p, ntiles);

@@ -34,9 +34,6 @@
 #ifndef V3D_GEMM_TAPINNER_DEFAULT
 #define V3D_GEMM_TAPINNER_DEFAULT 0
 #endif
-#ifndef V3D_GEMM_V4_DEFAULT
-#define V3D_GEMM_V4_DEFAULT 0
-#endif
 
 namespace {
 
@@ -637,6 +634,27 @@ float* splitk_workspace(size_t floats, hipStream_t st) {
     return s.ptr;
 }
 
+// ---- launch record (tests / tools / bench.py --shard-sim): what the last v3d_gemm of this thread actually launched --------------------------------
+// family (1 = v1, 2 = v2, 3 = v3 persistent, 5 = LDS-haloed (conv.hip)), tile, tile count, co-resident blocks per CU (the runtime's occupancy
+// answer for that kernel), split-K ways, stream-K tail.  Read back through v3d_debug_last_gemm_launch.
+thread_local V3dLaunchInfo g_last_launch = {0, 0, 0, 0, 0, 0, 0};
+template <typename K>
+int v3d_occupancy(K kernel, int threads) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 1;
+    }
+    return n;
+}
+void v3d_note_launch_splitk(int ways) { g_last_launch.splitk = ways; }
+#define V3D_LAUNCH(FAM, BM_, BN_, TILES, KERNEL, GRID, THREADS, ST, ...)                               \
+    do {                                                                                             \
+        static const int occ_ = v3d_occupancy(KERNEL, THREADS);                                      \
+        v3d_note_launch(FAM, BM_, BN_, (long long)(TILES), occ_, 0);                                 \
+        hipLaunchKernelGGL(KERNEL, GRID, dim3(THREADS), 0, ST, __VA_ARGS__);                         \
+    } while (0)
+
 int impl_choice() {
     static int v = -1;
     if (v < 0) {
@@ -693,10 +711,11 @@ int launch(const GP& p0, int batch, hipStream_t st) {
                 q.bias = nullptr; q.add = nullptr; q.res1 = nullptr; q.res2 = nullptr; q.coef = nullptr;
                 q.c_acc = 1.f; q.c_res1 = 0.f; q.c_res2 = 0.f;
                 dim3 g2((unsigned)(p.mt * p.nt), (unsigned)want, 1);
-                hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), g2, dim3(256), 0, st, q);
+                V3D_LAUNCH(2, BM, BN, (long long)g2.x * g2.y, (gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), g2, 256, st, q);
                 p.split_n = want;
                 p.ws = ws;
                 const long long n4 = p.M * (p.N / 4);
+                v3d_note_launch_splitk(want);
                 hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p);
                 return v3d_check_launch("v3d_gemm(split-K)");
             }
@@ -704,7 +723,7 @@ int launch(const GP& p0, int batch, hipStream_t st) {
     }
     if (impl_choice() == 1 || p.K % 32 != 0 || p.K * 2 > 65536) {   // (impl 0 / 2 / 3 all land here for v2-class shapes)
         // v1 also serves ragged contractions (K % 32 != 0: the 8-channel input conv, odd test shapes)
-        hipLaunchKernelGGL((gemm_kernel_v1<BM, BN, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+        V3D_LAUNCH(1, BM, BN, (long long)grid.x * grid.y, (gemm_kernel_v1<BM, BN, MODE, GEGLU>), grid, 256, st, p);
         return v3d_check_launch("v3d_gemm");
     }
     int cfg = cfg_choice();
@@ -724,10 +743,10 @@ int launch(const GP& p0, int batch, hipStream_t st) {
     if (p.K % 64 != 0 && (cfg == 1 || cfg == 4 || cfg == 7 || cfg == 9)) cfg = (cfg == 4) ? 3 : (cfg == 9 ? 8 : 0);   // BK 64 stages need K % 64 == 0
     switch (cfg) {
         case 1:   // BK 64 stages, 2 deep (one in flight)
-            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            V3D_LAUNCH(2, BM, BN, (long long)grid.x * grid.y, (gemm_kernel_v2<BM, BN, 2, 2, 2, 2, MODE, GEGLU>), grid, 256, st, p);
             break;
         case 2:   // BK 32 stages, 3 deep: 3 blocks / CU
-            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 3, 1, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            V3D_LAUNCH(2, BM, BN, (long long)grid.x * grid.y, (gemm_kernel_v2<BM, BN, 2, 2, 3, 1, MODE, GEGLU>), grid, 256, st, p);
             break;
         case 3:   // 256 x 128 tile, 8 waves (4 x 2), BK 32 x 4 stages (N tiles of 64 keep the 4-wave kernel)
         case 4:   // 256 x 128 tile, 8 waves, BK 64 x 3 stages
@@ -735,9 +754,9 @@ int launch(const GP& p0, int batch, hipStream_t st) {
                 p.mt = (int)((p.M + 255) / 256);
                 dim3 g2((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
                 if (cfg == 3)
-                    hipLaunchKernelGGL((gemm_kernel_v2<256, BN, 4, 2, 4, 1, MODE, GEGLU>), g2, dim3(512), 0, st, p);
+                    V3D_LAUNCH(2, 256, BN, (long long)g2.x * g2.y, (gemm_kernel_v2<256, BN, 4, 2, 4, 1, MODE, GEGLU>), g2, 512, st, p);
                 else
-                    hipLaunchKernelGGL((gemm_kernel_v2<256, BN, 4, 2, 3, 2, MODE, GEGLU>), g2, dim3(512), 0, st, p);
+                    V3D_LAUNCH(2, 256, BN, (long long)g2.x * g2.y, (gemm_kernel_v2<256, BN, 4, 2, 3, 2, MODE, GEGLU>), g2, 512, st, p);
                 break;
             }
             [[fallthrough]];
@@ -745,15 +764,15 @@ int launch(const GP& p0, int batch, hipStream_t st) {
             if constexpr (BN == 128) {
                 p.mt = (int)((p.M + 255) / 256);
                 dim3 g2((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
-                hipLaunchKernelGGL((gemm_kernel_v2<256, 128, 2, 2, 3, 1, MODE, GEGLU>), g2, dim3(256), 0, st, p);
+                V3D_LAUNCH(2, 256, 128, (long long)g2.x * g2.y, (gemm_kernel_v2<256, 128, 2, 2, 3, 1, MODE, GEGLU>), g2, 256, st, p);
                 break;
             }
             [[fallthrough]];
         case 10:  // BK 32 stages, 2 deep: 32 KiB LDS -> 4 blocks / CU (VGPR-limited)
-            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 2, 1, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            V3D_LAUNCH(2, BM, BN, (long long)grid.x * grid.y, (gemm_kernel_v2<BM, BN, 2, 2, 2, 1, MODE, GEGLU>), grid, 256, st, p);
             break;
         case 7:   // BK 64 stages, 3 deep
-            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 3, 2, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            V3D_LAUNCH(2, BM, BN, (long long)grid.x * grid.y, (gemm_kernel_v2<BM, BN, 2, 2, 3, 2, MODE, GEGLU>), grid, 256, st, p);
             break;
         case 8:   // 256 x 64 tile, 4 waves stacked along M (wave tile 64 x 64), BK 32 x 3
         case 9:   // 256 x 64 tile, 4 waves, BK 64 x 2
@@ -761,14 +780,14 @@ int launch(const GP& p0, int batch, hipStream_t st) {
                 p.mt = (int)((p.M + 255) / 256);
                 dim3 g2((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
                 if (cfg == 8)
-                    hipLaunchKernelGGL((gemm_kernel_v2<256, 64, 4, 1, 3, 1, MODE, GEGLU>), g2, dim3(256), 0, st, p);
+                    V3D_LAUNCH(2, 256, 64, (long long)g2.x * g2.y, (gemm_kernel_v2<256, 64, 4, 1, 3, 1, MODE, GEGLU>), g2, 256, st, p);
                 else
-                    hipLaunchKernelGGL((gemm_kernel_v2<256, 64, 4, 1, 2, 2, MODE, GEGLU>), g2, dim3(256), 0, st, p);
+                    V3D_LAUNCH(2, 256, 64, (long long)g2.x * g2.y, (gemm_kernel_v2<256, 64, 4, 1, 2, 2, MODE, GEGLU>), g2, 256, st, p);
                 break;
             }
             [[fallthrough]];
         default:  // cfg 0: BK 32 stages, 4 deep
-            hipLaunchKernelGGL((gemm_kernel_v2<BM, BN, 2, 2, 4, 1, MODE, GEGLU>), grid, dim3(256), 0, st, p);
+            V3D_LAUNCH(2, BM, BN, (long long)grid.x * grid.y, (gemm_kernel_v2<BM, BN, 2, 2, 4, 1, MODE, GEGLU>), grid, 256, st, p);
     }
     return v3d_check_launch("v3d_gemm");
 }
@@ -780,9 +799,9 @@ int launch256(const GP& p0, int batch, hipStream_t st, int cfg) {
     p.nt = (int)((p.N + 255) / 256);
     dim3 grid((unsigned)(p.mt * p.nt), (unsigned)batch, 1);
     if (cfg == 5)
-        hipLaunchKernelGGL((gemm_kernel_v2<256, 256, 4, 2, 3, 1, MODE, GEGLU>), grid, dim3(512), 0, st, p);
+        V3D_LAUNCH(2, 256, 256, (long long)grid.x * grid.y, (gemm_kernel_v2<256, 256, 4, 2, 3, 1, MODE, GEGLU>), grid, 512, st, p);
     else
-        hipLaunchKernelGGL((gemm_kernel_v2<256, 256, 4, 2, 2, 2, MODE, GEGLU>), grid, dim3(512), 0, st, p);
+        V3D_LAUNCH(2, 256, 256, (long long)grid.x * grid.y, (gemm_kernel_v2<256, 256, 4, 2, 2, 2, MODE, GEGLU>), grid, 512, st, p);
     return v3d_check_launch("v3d_gemm");
 }
 
@@ -823,14 +842,14 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
     const int grid = ntiles < v3d_num_cus() ? ntiles : v3d_num_cus();
     if constexpr (MODE == V3D_GEMM_LINEAR && !GEGLU) {
         if V3D_ABL(p, 8) {
-            hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            V3D_LAUNCH(3, 256, 256, ntiles, (gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, true>), dim3(grid), 512, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
     }
     if constexpr (GEGLU && MODE == V3D_GEMM_LINEAR) {
         if (variant == 2) {   // epilogue-bound GEGLU projections (K = 320): 256 x 128 tile, two blocks per CU
             const int g2 = ntiles < 2 * v3d_num_cus() ? ntiles : 2 * v3d_num_cus();
-            hipLaunchKernelGGL((gemm_kernel_v3<256, 128, 4, 2, MODE, GEGLU, 1, false, 3, 0>), dim3(g2), dim3(512), 0, st, p, ntiles);
+            V3D_LAUNCH(3, 256, 128, ntiles, (gemm_kernel_v3<256, 128, 4, 2, MODE, GEGLU, 1, false, 3, 0>), dim3(g2), 512, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
     }
@@ -841,16 +860,16 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
             if (p.gn_stats && 80 % p.gn_cpg == 0 && p.gn_nslots >= p.gn_rps / 96 + 2) {
                 g_gn_in_epilogue = true;
                 ++g_gn_epilogue_launches;
-                hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
+                V3D_LAUNCH(3, 192, 320, ntiles, (gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), 512, st, p, ntiles);
             } else {
-                hipLaunchKernelGGL((gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+                V3D_LAUNCH(3, 192, 320, ntiles, (gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1>), dim3(grid), 512, st, p, ntiles);
             }
             return v3d_check_launch("v3d_gemm");
         }
         if (p.gn_stats && variant == 0 && 64 % p.gn_cpg == 0 && p.gn_nslots >= p.gn_rps / 128 + 2) {
             g_gn_in_epilogue = true;
             ++g_gn_epilogue_launches;
-            hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            V3D_LAUNCH(3, 256, 256, ntiles, (gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, false, 4, 16, true>), dim3(grid), 512, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
     }
@@ -860,12 +879,12 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
         // measured (tools/gemm_floor.py, M = 147456, N = 2560): K = 320: 396 us vs 416 us (2 x 4) vs 402 us (two 256 x 128 blocks
         // per CU) vs 421 us (v2); at K >= 640 the 2 x 4 layout with 32-row chunks is ahead again (tools/gemm_sweep.py)
         if (p.K < 640 && !V3D_ABL(p, 128)) {
-            hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 4, 2, MODE, GEGLU, 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+            V3D_LAUNCH(3, 256, 256, ntiles, (gemm_kernel_v3<256, 256, 4, 2, MODE, GEGLU, 1>), dim3(grid), 512, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
     }
     // epilogue chunk: 2 row fragments for GEGLU (its staged rows are half as wide), 1 otherwise (LDS budget next to the ring)
-    hipLaunchKernelGGL((gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, GEGLU ? 2 : 1>), dim3(grid), dim3(512), 0, st, p, ntiles);
+    V3D_LAUNCH(3, 256, 256, ntiles, (gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, GEGLU ? 2 : 1>), dim3(grid), 512, st, p, ntiles);
     return v3d_check_launch("v3d_gemm");
 }
 
@@ -893,12 +912,13 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
         // (non-GEGLU v3 kernels only carry the hand-managed epilogue: its operand contract on top of the tile-shape one)
         const bool eok = GEGLU || (variant ? e4_ok(p, 96, 80) : e4_ok(p, 128, 64));
         if (want && eok && (variant ? v3_ok(p, 96, 80) : v3_ok(p, 128, 128))) {
+#ifdef V3D_EXPERIMENTS
             if constexpr (!GEGLU) {
-                // one wave per SIMD, software-pipelined in the wave (gemm4.hip): V3D_GEMM_V4 = 0 never, 1 = every launch it can take
+                // lab only (tools/lab/gemm4.hip, linked into the experiments library): the one-wave-per-SIMD kernels of round 4, V3D_GEMM_V4=1
                 static int v4 = -1;
                 if (v4 < 0) {
                     const char* e = getenv("V3D_GEMM_V4");
-                    v4 = e ? atoi(e) : V3D_GEMM_V4_DEFAULT;
+                    v4 = e ? atoi(e) : 0;
                 }
                 const int v4v = v4 ? v3d_gemm_v4_variant(p, MODE, variant) : 0;
                 if (v4v) {
@@ -909,6 +929,7 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
                     return v3d_gemm_v4_launch(p, MODE, v4v, (void*)st);
                 }
             }
+#endif
             return launch_v3<MODE, GEGLU>(p, st, variant);
         }
     }
@@ -921,6 +942,17 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
 }
 
 }  // namespace
+
+void v3d_note_launch(int family, int bm, int bn, long long tiles, int blocks_per_cu, int streamk) {
+    g_last_launch = V3dLaunchInfo{family, bm, bn, tiles, blocks_per_cu, 0, streamk};
+}
+
+// tests / tools only (not part of the ABI header): out[8] = family, bm, bn, tiles, blocks per CU, split-K ways, stream-K tail, CUs
+extern "C" int v3d_debug_last_gemm_launch(long long* out) {
+    out[0] = g_last_launch.family; out[1] = g_last_launch.bm; out[2] = g_last_launch.bn; out[3] = g_last_launch.tiles;
+    out[4] = g_last_launch.blocks_per_cu; out[5] = g_last_launch.splitk; out[6] = g_last_launch.streamk; out[7] = v3d_num_cus();
+    return 0;
+}
 
 // tests only (not part of the ABI header)
 extern "C" long long v3d_debug_gn_epilogue_launches(void) { return g_gn_epilogue_launches; }

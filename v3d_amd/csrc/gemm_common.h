@@ -62,12 +62,22 @@ struct V3dGemmParams {
     unsigned* sk_flags;  // [G][8]: 1 = wave w of block g has published its partial (reset to 0 by the consumer)
 };
 
+// gemm.hip: record of the last launch v3d_gemm made on this thread (v3d_debug_last_gemm_launch)
+struct V3dLaunchInfo {
+    int family, bm, bn;
+    long long tiles;
+    int blocks_per_cu, splitk, streamk;
+};
+void v3d_note_launch(int family, int bm, int bn, long long tiles, int blocks_per_cu, int streamk);
 // conv.hip: the LDS-haloed kernels (GroupNorm + SiLU in the operand path)
 int v3d_conv_halo_variant(const V3dGemmParams& p, int mode);          // 0 = not one of their shapes
 int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream);
-// gemm4.hip: the one-wave-per-SIMD persistent kernels (0 = not one of their launches, else the variant: 1 = 192 x 320 tiles, 2 = 256 x 256)
+#ifdef V3D_EXPERIMENTS
+// tools/lab/gemm4.hip (experiments library only): the one-wave-per-SIMD persistent kernels of round 4 (0 = not one of their launches, else the
+// variant: 1 = 192 x 320 tiles, 2 = 256 x 256).  5 % slower than v3 (NOTES 11.2): kept as a lab record, not part of the product library.
 int v3d_gemm_v4_variant(const V3dGemmParams& p, int mode, int v3_variant);
 int v3d_gemm_v4_launch(const V3dGemmParams& p, int mode, int variant, void* stream);
+#endif
 // gemm.hip: stream-K plan of a persistent launch (fills p.sk_*, returns the grid): ntiles tiles of `units` split granules on the device's CUs;
 // slot_bytes = one block's accumulators in fp32.  Leaves the classic assignment (sk_tail = 0) when the tail round is full enough or too thin.
 int v3d_sk_plan(V3dGemmParams& p, int ntiles, int units, int min_units, int min_saved, size_t slot_bytes, void* stream);
@@ -974,6 +984,8 @@ __device__ __forceinline__ void sk_gather(const GP& p, f32x4 (&acc)[MF][NF], int
 inline bool e4_ok(const V3dGemmParams& p, int wm, int wn) {
     auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
     if (p.out_fp32 || p.M % wm || p.N % wn || p.ldo % 8 || !al(p.out, 16)) return false;
+    // the epilogue tracks rows and row-group remainders in 32 bits (e4_udiv on (unsigned)m0f, E4GnRun): larger launches take the generic epilogue
+    if (p.M >= (1ll << 32) || (p.add && p.add_rpg >= (1ll << 32)) || (p.coef && p.coef_rpg >= (1ll << 32))) return false;
     if (p.bias && !al(p.bias, 16)) return false;
     if (p.add && (!al(p.add, 16) || p.add_ld % 4 || p.add_rpg % 16)) return false;
     if (p.res1 && (!al(p.res1, 16) || p.ldr1 % 8)) return false;

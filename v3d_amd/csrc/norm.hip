@@ -35,6 +35,99 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
     f[4] = bflo(u.z); f[5] = bfhi(u.z); f[6] = bflo(u.w); f[7] = bfhi(u.w);
 }
 
+// One block per statistics group: the slots' partial sums are added up in a FIXED order in fp64 (NT / 16 slot lanes per (group, component), then
+// the lanes in order), mean / variance / rstd in fp64 (E[x^2] - E[x]^2 cancels in fp64, not fp32: inputs with |mean| >> std keep their
+// variance), and the per-(statistics group, channel) affine of the normalisation is written as a table
+//   table[stat][c] = (scale, shift) = (gamma[c] rstd[g],  beta[c] - mean[g] gamma[c] rstd[g])          y = x * scale + shift
+// which is all a consumer needs: v3d_groupnorm_apply, and the convolutions that normalise their input tile on its way into LDS
+// (v3d_gemm gn_in_table).  `sums` [n_stat][groups][2] fp64 is the frame-sharded runtime's hand-off: written when the slots are given,
+// read (after the all-reduce over ranks) when they are not.
+// The body runs on NT threads of ONE block with `smem` >= gn_fin_smem<NT>() bytes (8-byte aligned): as its own kernel (NT = 1024), and at
+// the end of gn_stats_kernel<.., FUSE> on the 256 threads of the LAST block of a statistics group to finish (round 5: v3d_groupnorm_stats_table).
+template <int NT>
+__host__ __device__ constexpr int gn_fin_smem() { return (NT / 16) * 64 * 8 + 64 * 8 + 64 * 4; }
+
+template <int NT>
+__device__ __forceinline__ void gn_finalize_block(unsigned char* smem, const float* __restrict__ stats, long long nslots, long long nsum, double* __restrict__ sums,
+                                                  int groups, const float* __restrict__ gamma, const float* __restrict__ beta, long long C,
+                                                  double inv_count, float eps, float* __restrict__ table, long long st) {
+    // NT threads: NT / 16 slot lanes x 16 float4 columns of a slot row (groups * 2 <= 64 floats); every lane adds its slots (stride NT / 16) in
+    // fp64 with 4 independent loads in flight, the lanes meet in LDS and are added in lane order - a fixed order whatever the scheduling.
+    // (The first version walked the slots with 4 lanes of 64 threads: 45 us per launch for the 1154 slots of a 64x64-level 3-D norm.)
+    constexpr int LANES = NT / 16, QL = LANES / 4;
+    double (*part)[64] = reinterpret_cast<double (*)[64]>(smem);
+    double* tot = reinterpret_cast<double*>(smem + LANES * 64 * 8);
+    float* ms = reinterpret_cast<float*>(smem + LANES * 64 * 8 + 64 * 8);           // [group][2]: mean, rstd
+    const int tid = threadIdx.x;
+    const int npair = groups * 2;      // <= 64, % 4 == 0 (host-checked)
+    const int vec = tid & 15, sl = tid >> 4;
+    if (stats) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (vec * 4 < npair) {
+            const float* sp = stats + (st * nslots) * npair + vec * 4;
+            long long k = sl;
+            for (; k + 3 * LANES < nsum; k += 4 * LANES) {          // (nsum <= nslots: the slots to add; nslots = the slot stride of a statistics group)
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
+                const float4 v1 = *reinterpret_cast<const float4*>(sp + (k + LANES) * npair);
+                const float4 v2 = *reinterpret_cast<const float4*>(sp + (k + 2 * LANES) * npair);
+                const float4 v3 = *reinterpret_cast<const float4*>(sp + (k + 3 * LANES) * npair);
+                a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+                a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+                a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+                a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+            }
+            for (; k < nsum; k += LANES) {
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
+                a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
+            }
+        }
+        part[sl][vec * 4 + 0] = a0;
+        part[sl][vec * 4 + 1] = a1;
+        part[sl][vec * 4 + 2] = a2;
+        part[sl][vec * 4 + 3] = a3;
+        __syncthreads();
+        // the lanes of a pair: a fixed binary tree (4 threads per pair add LANES / 4 lanes each in order, then ((0 + 1) + (2 + 3)))
+        if (tid < npair * 4) {
+            const int pr = tid >> 2, q = tid & 3;
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < QL; ++l) a += part[q * QL + l][pr];
+            part[q * QL][pr] = a;          // (only this thread reads rows q * QL .. q * QL + QL - 1 of column pr)
+        }
+        __syncthreads();
+        if (tid < npair) {
+            const double a = (part[0][tid] + part[QL][tid]) + (part[2 * QL][tid] + part[3 * QL][tid]);
+            tot[tid] = a;
+            if (sums) sums[st * npair + tid] = a;
+        }
+    } else if (tid < npair) {
+        tot[tid] = sums[st * npair + tid];
+    }
+    __syncthreads();
+    if (!table) return;
+    if (tid < groups) {
+        const double mean = tot[tid * 2] * inv_count;
+        double var = tot[tid * 2 + 1] * inv_count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        ms[tid * 2] = (float)mean;
+        ms[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = (int)(C / groups);
+    for (long long c = tid; c < C; c += NT) {
+        const int gidx = (int)(c / cpg);
+        const float sc = gamma[c] * ms[gidx * 2 + 1];
+        *reinterpret_cast<float2*>(table + (st * C + c) * 2) = make_float2(sc, beta[c] - ms[gidx * 2] * sc);
+    }
+}
+
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ stats, long long nslots, double* __restrict__ sums, int groups,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, long long C,
+                                                           double inv_count, float eps, float* __restrict__ table) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[gn_fin_smem<1024>()];
+    gn_finalize_block<1024>(smem, stats, nslots, nslots, sums, groups, gamma, beta, C, inv_count, eps, table, (long long)blockIdx.x);
+}
+
 // grid (chunks, n_img); block 256.  Each block reduces rows [chunk*rpb, (chunk+1)*rpb) of one image and stores its (sum, sumsq) per
 // group into ITS OWN slot of the statistics buffer: slot = (img % imgs_per_stat) * chunks + chunk - plain stores, no atomics anywhere,
 // so the statistics (and with them every GroupNorm output) are bit-reproducible run to run.  (Rounds 1-2 met in fp32 atomics: LDS atomics
@@ -42,11 +135,24 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
 // NV (vector columns per thread) is a template parameter and the per-channel LDS partials are sized by C (dynamic shared
 // memory): the first version carried the dead second column through every load / fma and declared 32 KiB of LDS, which
 // capped a CU at 5 blocks - 56 us for the 94 MB 64x64 level where the read+write gn_apply takes 36 us.
-template <int NV, int UR>
+// FUSE (round 5, v3d_groupnorm_stats_table): the block takes a ticket per statistics group once its slot is written and visible; the LAST block of
+// a group to arrive folds the group's slots into the (scale, shift) table right here (gn_finalize_block on its 256 threads) - the separate
+// finalize launch (7-11 us of launch-bound time, 41 per U-Net evaluation behind stand-alone statistics passes) disappears.  Which block is
+// last varies run to run; what it computes does not (fixed slot order, fp64): the table stays bit-reproducible.
+struct GNFuse {
+    unsigned* tickets;      // [n_stat], zero on entry, reset to zero by the last block
+    const float* gamma;
+    const float* beta;
+    float* table;
+    double inv_count;
+    float eps;
+};
+
+template <int NV, int UR, bool FUSE = false>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x1, long long C1,
                                                        const bf16_t* __restrict__ x2, long long C2,
                                                        float* __restrict__ stats, long long nslots, long long S, int groups,
-                                                       long long imgs_per_stat, long long rpb) {
+                                                       long long imgs_per_stat, long long rpb, GNFuse fz) {
     extern __shared__ float gn_sh[];   // [2][RPP][C]: per (row lane, channel) sum, sum of squares
     const long long C = C1 + C2;
     const GNGeom g = gn_geom(C);
@@ -119,85 +225,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
         dst[0] = a;
         dst[1] = b;
     }
-}
-
-// One block per statistics group: the slots' partial sums are added up in a FIXED order in fp64 (4 slot lanes per (group, component), then
-// the 4 lanes in order), mean / variance / rstd in fp64 (E[x^2] - E[x]^2 cancels in fp64, not fp32: inputs with |mean| >> std keep their
-// variance), and the per-(statistics group, channel) affine of the normalisation is written as a table
-//   table[stat][c] = (scale, shift) = (gamma[c] rstd[g],  beta[c] - mean[g] gamma[c] rstd[g])          y = x * scale + shift
-// which is all a consumer needs: v3d_groupnorm_apply, and the convolutions that normalise their input tile on its way into LDS
-// (v3d_gemm gn_in_table).  `sums` [n_stat][groups][2] fp64 is the frame-sharded runtime's hand-off: written when the slots are given,
-// read (after the all-reduce over ranks) when they are not.
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ stats, long long nslots, double* __restrict__ sums, int groups,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta, long long C,
-                                                           double inv_count, float eps, float* __restrict__ table) {
-    // 1024 threads: 64 slot lanes x 16 float4 columns of a slot row (groups * 2 <= 64 floats); every lane adds its slots (stride 64) in fp64
-    // with 4 independent loads in flight, the lanes meet in LDS and are added in lane order - a fixed order whatever the scheduling.
-    // (The first version walked the slots with 4 lanes of 64 threads: 45 us per launch for the 1154 slots of a 64x64-level 3-D norm.)
-    __shared__ double part[64][64];
-    __shared__ double tot[64];
-    __shared__ float ms[64];           // [group][2]: mean, rstd
-    const int tid = threadIdx.x;
-    const long long st = blockIdx.x;
-    const int npair = groups * 2;      // <= 64, % 4 == 0 (host-checked)
-    const int vec = tid & 15, sl = tid >> 4;
-    if (stats) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        if (vec * 4 < npair) {
-            const float* sp = stats + (st * nslots) * npair + vec * 4;
-            long long k = sl;
-            for (; k + 192 < nslots; k += 256) {
-                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
-                const float4 v1 = *reinterpret_cast<const float4*>(sp + (k + 64) * npair);
-                const float4 v2 = *reinterpret_cast<const float4*>(sp + (k + 128) * npair);
-                const float4 v3 = *reinterpret_cast<const float4*>(sp + (k + 192) * npair);
-                a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-                a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-                a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
-                a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
-            }
-            for (; k < nslots; k += 64) {
-                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
-                a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
-            }
-        }
-        part[sl][vec * 4 + 0] = a0;
-        part[sl][vec * 4 + 1] = a1;
-        part[sl][vec * 4 + 2] = a2;
-        part[sl][vec * 4 + 3] = a3;
+    if constexpr (FUSE) {
+        __shared__ unsigned ticket;
+        const long long st = img / imgs_per_stat;
+        const unsigned writers = (unsigned)(gridDim.x * imgs_per_stat);        // blocks of this statistics group = slots it fills (slots 0 .. writers - 1)
+        __threadfence();                     // the slot stores above are visible device-wide before the ticket is taken (release)
         __syncthreads();
-        // the 64 lanes of a pair: a fixed binary tree (4 threads per pair add 16 lanes each in order, then ((0 + 1) + (2 + 3)))
-        if (tid < npair * 4) {
-            const int pr = tid >> 2, q = tid & 3;
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < 16; ++l) a += part[q * 16 + l][pr];
-            part[q * 16][pr] = a;          // (only this thread reads rows q * 16 .. q * 16 + 15 of column pr)
-        }
+        if (tid == 0) ticket = __hip_atomic_fetch_add(fz.tickets + st, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (tid < npair) {
-            const double a = (part[0][tid] + part[16][tid]) + (part[32][tid] + part[48][tid]);
-            tot[tid] = a;
-            if (sums) sums[st * npair + tid] = a;
-        }
-    } else if (tid < npair) {
-        tot[tid] = sums[st * npair + tid];
-    }
-    __syncthreads();
-    if (!table) return;
-    if (tid < groups) {
-        const double mean = tot[tid * 2] * inv_count;
-        double var = tot[tid * 2 + 1] * inv_count - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        ms[tid * 2] = (float)mean;
-        ms[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-    const int cpg = (int)(C / groups);
-    for (long long c = tid; c < C; c += 1024) {
-        const int gidx = (int)(c / cpg);
-        const float sc = gamma[c] * ms[gidx * 2 + 1];
-        *reinterpret_cast<float2*>(table + (st * C + c) * 2) = make_float2(sc, beta[c] - ms[gidx * 2] * sc);
+        if (ticket != writers - 1) return;   // (block-uniform)
+        __threadfence();                     // acquire: the other blocks' slots
+        // the per-channel partials in gn_sh are dead (read above, barrier passed): the fold uses the same LDS
+        gn_finalize_block<256>(reinterpret_cast<unsigned char*>(gn_sh), stats, nslots, (long long)writers, nullptr, groups, fz.gamma, fz.beta, C, fz.inv_count, fz.eps,
+                               fz.table, st);
+        if (tid == 0) __hip_atomic_store(fz.tickets + st, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
     }
 }
 
@@ -400,12 +441,13 @@ int gn_check(const char* who, const void* x1, long long C1, const void* x2, long
 
 }  // namespace
 
-extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots,
-                                   int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, v3d_stream_t stream) {
-    int rc = gn_check("v3d_groupnorm_stats", x1, C1, x2, C2, n_img, S, groups);
+namespace {
+int gn_stats_launch(const char* who, const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots, int64_t n_img, int64_t S,
+                    int32_t groups, int64_t imgs_per_stat, const GNFuse* fz, v3d_stream_t stream) {
+    int rc = gn_check(who, x1, C1, x2, C2, n_img, S, groups);
     if (rc) return rc;
-    V3D_REQUIRE(stats != nullptr && imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "v3d_groupnorm_stats: bad stats/imgs_per_stat");
-    V3D_REQUIRE(nslots >= imgs_per_stat, "v3d_groupnorm_stats: nslots (%lld) must be >= imgs_per_stat (%lld): one slot per block",
+    V3D_REQUIRE(stats != nullptr && imgs_per_stat > 0 && n_img % imgs_per_stat == 0, "%s: bad stats/imgs_per_stat", who);
+    V3D_REQUIRE(nslots >= imgs_per_stat, "%s: nslots (%lld) must be >= imgs_per_stat (%lld): one slot per block", who,
                 (long long)nslots, (long long)imgs_per_stat);
     const GNGeom g = gn_geom(C1 + C2);
     long long chunks, rpb;
@@ -424,15 +466,42 @@ extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, i
         chunks = (S + rpb - 1) / rpb;
     }
     const size_t shmem = (size_t)(C1 + C2) * 2 * g.RPP * sizeof(float);
-    V3D_REQUIRE(shmem <= 64 * 1024, "v3d_groupnorm_stats: C=%lld needs %zu B of LDS", (long long)(C1 + C2), shmem);
+    V3D_REQUIRE(shmem <= 64 * 1024, "%s: C=%lld needs %zu B of LDS", who, (long long)(C1 + C2), shmem);
+    V3D_REQUIRE(!fz || shmem >= (size_t)gn_fin_smem<256>(), "%s: C=%lld leaves %zu B of LDS for the fold", who, (long long)(C1 + C2), shmem);
     const dim3 grid((unsigned)chunks, (unsigned)n_img);
-    if (g.NV == 1)
-        hipLaunchKernelGGL((gn_stats_kernel<1, 8>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
-                           (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb);
-    else
-        hipLaunchKernelGGL((gn_stats_kernel<2, 4>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
-                           (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb);
-    return v3d_check_launch("v3d_groupnorm_stats");
+    const GNFuse none = {nullptr, nullptr, nullptr, nullptr, 0.0, 0.f};
+    if (g.NV == 1) {
+        if (fz)
+            hipLaunchKernelGGL((gn_stats_kernel<1, 8, true>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                               (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb, *fz);
+        else
+            hipLaunchKernelGGL((gn_stats_kernel<1, 8>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                               (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb, none);
+    } else {
+        if (fz)
+            hipLaunchKernelGGL((gn_stats_kernel<2, 4, true>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                               (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb, *fz);
+        else
+            hipLaunchKernelGGL((gn_stats_kernel<2, 4>), grid, dim3(256), shmem, (hipStream_t)stream, (const bf16_t*)x1, (long long)C1,
+                               (const bf16_t*)x2, (long long)C2, stats, (long long)nslots, (long long)S, groups, (long long)imgs_per_stat, rpb, none);
+    }
+    return v3d_check_launch(who);
+}
+}  // namespace
+
+extern "C" int v3d_groupnorm_stats(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots,
+                                   int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, v3d_stream_t stream) {
+    return gn_stats_launch("v3d_groupnorm_stats", x1, C1, x2, C2, stats, nslots, n_img, S, groups, imgs_per_stat, nullptr, stream);
+}
+
+extern "C" int v3d_groupnorm_stats_table(const void* x1, int64_t C1, const void* x2, int64_t C2, float* stats, int64_t nslots, uint32_t* tickets,
+                                         int64_t n_img, int64_t S, int32_t groups, int64_t imgs_per_stat, const float* gamma, const float* beta,
+                                         double count, float eps, float* table, v3d_stream_t stream) {
+    V3D_REQUIRE(tickets && gamma && beta && table && count > 0, "v3d_groupnorm_stats_table: null tickets / gamma / beta / table or count <= 0");
+    V3D_REQUIRE(groups > 0 && groups <= 32 && groups % 2 == 0, "v3d_groupnorm_stats_table: groups must be even and <= 32");
+    V3D_REQUIRE(((uintptr_t)stats & 15) == 0 && ((uintptr_t)table & 7) == 0 && ((uintptr_t)tickets & 3) == 0, "v3d_groupnorm_stats_table: stats 16-byte, table 8-byte aligned");
+    const GNFuse fz = {tickets, gamma, beta, table, 1.0 / count, eps};
+    return gn_stats_launch("v3d_groupnorm_stats_table", x1, C1, x2, C2, stats, nslots, n_img, S, groups, imgs_per_stat, &fz, stream);
 }
 
 extern "C" int v3d_groupnorm_finalize(const float* stats, int64_t nslots, double* sums, int64_t n_stat, int32_t groups,

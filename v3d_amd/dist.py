@@ -307,9 +307,14 @@ class SimFrameShard(FrameShard):
     def _exchange(self, sends, recvs, async_op: bool = False) -> _Handle:
         self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
         self.n_exchanges += 1 if (sends or recvs) else 0
-        src = sends[0][0].reshape(-1) if sends else None
+        # every receive buffer is fed from this rank's own send OF THE SAME DTYPE (the bf16 halo from the bf16 halo, the fp64 GroupNorm sums
+        # from the fp64 sums: other ranks' statistics = this rank's), repeated / cut to the receive's size
+        by_dtype = {}
+        for t, _ in sends:
+            by_dtype.setdefault(t.dtype, t.reshape(-1))
         for t, _ in recvs:
-            if src is None or src.dtype != t.dtype:
+            src = by_dtype.get(t.dtype)
+            if src is None:
                 t.zero_()
                 continue
             flat = t.reshape(-1) if t.is_contiguous() else None

@@ -16,7 +16,7 @@ from .ops import GemmCall, OpsBase
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("V3D_HIP_LIB") or os.path.join(_HERE, "lib", "libv3d_hip.so")     # (override: A/B runs of two builds on one box)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i64, c_i32, c_f32, c_f64, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_void_p
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     "v3d_ln_proj": (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, c_vp]),
     "v3d_gemm_gn_in_supported": (c_i32, [C.POINTER(_GemmArgs)]),
     "v3d_groupnorm_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_i64, c_vp]),
+    "v3d_groupnorm_stats_table": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_vp, C.c_double, C.c_float, c_vp, c_vp]),
     "v3d_groupnorm_finalize": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_f64, c_f32, c_vp, c_vp]),
     "v3d_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "v3d_groupnorm_small_supported": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i64]),
@@ -139,6 +140,20 @@ class HipOps(OpsBase):
         fn = self.lib.v3d_debug_sk_timeouts
         fn.restype, fn.argtypes = C.c_longlong, []
         return int(fn())
+
+    def last_gemm_launch(self) -> dict:
+        """What the last `gemm` of this thread actually launched (the library's own record, gemm.hip v3d_debug_last_gemm_launch): kernel family
+        (1 = v1, 2 = v2, 3 = persistent v3, 5 = LDS-haloed), tile, tile count, co-resident blocks per CU, split-K ways, stream-K tail - and `fill`,
+        the fraction of the CU slots the launch keeps busy over its rounds (1.0 with a stream-K tail: the last round is shared out)."""
+        fn = self.lib.v3d_debug_last_gemm_launch
+        fn.restype, fn.argtypes = c_i32, [c_vp]
+        o = (C.c_longlong * 8)()
+        fn(C.cast(o, c_vp))
+        fam, bm, bn, tiles, bpc, sk, tail, cus = (int(v) for v in o)
+        slots = max(1, bpc) * max(1, cus)
+        tiles_eff = tiles * max(1, sk)
+        fill = 1.0 if tail else tiles_eff / (-(-tiles_eff // slots) * slots) if tiles_eff else 0.0
+        return {"family": fam, "bm": bm, "bn": bn, "tiles": tiles, "blocks_per_cu": bpc, "splitk": sk, "streamk_tail": tail, "cus": cus, "fill": fill}
 
     def check_health(self):
         n = self.streamk_timeouts()
@@ -293,6 +308,19 @@ class HipOps(OpsBase):
         self._check(self.lib.v3d_groupnorm_stats(x1.data_ptr(), x1.shape[-1], _ptr(x2), 0 if x2 is None else x2.shape[-1],
                                                  stats.data_ptr(), stats.shape[1], n_img, S, groups, imgs_per_stat, self._stream()),
                     "v3d_groupnorm_stats")
+
+    def groupnorm_stats_table(self, x1, x2, stats, tickets, n_img, S, groups, imgs_per_stat, gamma, beta, count, eps, table):
+        """Statistics + (scale, shift) table in ONE launch (ABI 5): the last block of each statistics group folds the group's slots."""
+        bf, f32 = torch.bfloat16, torch.float32
+        self._req_c(x1, bf, "gn.x1")
+        if x2 is not None:
+            self._req_c(x2, bf, "gn.x2")
+        self._req_c(stats, f32, "gn.stats"); self._req_c(gamma, f32, "gn.gamma"); self._req_c(beta, f32, "gn.beta"); self._req_c(table, f32, "gn.table")
+        if tickets.dtype != torch.int32 or tickets.numel() < n_img // imgs_per_stat or not tickets.is_contiguous():
+            raise ValueError("gn.tickets: need a contiguous int32 tensor with one (zero) entry per statistics group")
+        self._check(self.lib.v3d_groupnorm_stats_table(x1.data_ptr(), x1.shape[-1], _ptr(x2), 0 if x2 is None else x2.shape[-1], stats.data_ptr(), stats.shape[1],
+                                                       tickets.data_ptr(), n_img, S, groups, imgs_per_stat, gamma.data_ptr(), beta.data_ptr(), float(count), float(eps),
+                                                       table.data_ptr(), self._stream()), "v3d_groupnorm_stats_table")
 
     def groupnorm_finalize(self, stats, sums, gamma, beta, count, eps, table):
         """stats [n_stat, nslots, groups, 2] fp32 (or None: read `sums`), sums [n_stat, groups, 2] fp64 (or None), table [n_stat, C, 2] fp32 (or None)."""

@@ -190,13 +190,19 @@ class OpsBase:
         count_imgs = number of images (global) contributing to one statistics group."""
         C = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
         n_stat = n_img // imgs_per_stat
-        if stats is None:
-            stats = self.gn_stats_buffer(n_stat, x1.device, groups, rps=imgs_per_stat * S, imgs_per_stat=imgs_per_stat)
-            self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
         if count_imgs is None:
             count_imgs = imgs_per_stat
         count = float(count_imgs) * S * (C // groups)
         table = self.empty((n_stat, C, 2), torch.float32, x1.device)
+        if stats is None and stats_hook is None and self._GN_FUSED_TABLE and groups <= 32 and groups % 2 == 0 and hasattr(self, "groupnorm_stats_table"):
+            # statistics + table in ONE launch (ABI 5): the last block of a statistics group folds its slots - no finalize launch
+            stats = self.gn_stats_buffer(n_stat, x1.device, groups, rps=imgs_per_stat * S, imgs_per_stat=imgs_per_stat)
+            tickets = self.zeros_f32_pooled((n_stat,), x1.device).view(torch.int32)
+            self.groupnorm_stats_table(x1, x2, stats, tickets, n_img, S, groups, imgs_per_stat, gamma, beta, count, eps, table)
+            return table
+        if stats is None:
+            stats = self.gn_stats_buffer(n_stat, x1.device, groups, rps=imgs_per_stat * S, imgs_per_stat=imgs_per_stat)
+            self.groupnorm_stats(x1, x2, stats, n_img, S, groups, imgs_per_stat)
         if stats_hook is None:
             self.groupnorm_finalize(stats, None, gamma, beta, count, eps, table)
         else:
@@ -224,6 +230,7 @@ class OpsBase:
         self.groupnorm_apply(x1, x2, table, out, n_img, S, imgs_per_stat, silu)
         return out
 
+    _GN_FUSED_TABLE = os.environ.get("V3D_GN_FUSED_TABLE", "1") not in ("", "0")      # A/B knob: 0 = stand-alone statistics pass + finalize launch
     _GN_SMALL = os.environ.get("V3D_GN_SMALL", "1") not in ("", "0")      # A/B knob: 0 = always statistics -> finalize -> apply
 
     def groupnorm_small_fits(self, x1, x2, S, imgs_per_stat=1, groups=32) -> bool:
