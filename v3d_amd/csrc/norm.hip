@@ -47,7 +47,23 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
 template <int NT>
 __host__ __device__ constexpr int gn_fin_smem() { return (NT / 16) * 64 * 8 + 64 * 8 + 64 * 4; }
 
-template <int NT>
+// four 16-byte loads that bypass the non-coherent cache levels (sc0 sc1: what another XCD's L2 may still hold is not what these return) - the
+// fused statistics kernel's last block reads slots other blocks wrote DURING THIS LAUNCH (gemm_common.h sk_gather reads partials the same way)
+__device__ __forceinline__ void gn_ld4_coherent(const float* p0, const float* p1, const float* p2, const float* p3, float4& v0, float4& v1, float4& v2, float4& v3) {
+    f32x4 a, b, c, d;
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+    v0 = make_float4(a[0], a[1], a[2], a[3]); v1 = make_float4(b[0], b[1], b[2], b[3]);
+    v2 = make_float4(c[0], c[1], c[2], c[3]); v3 = make_float4(d[0], d[1], d[2], d[3]);
+}
+
+template <int NT, bool COHERENT = false>
 __device__ __forceinline__ void gn_finalize_block(unsigned char* smem, const float* __restrict__ stats, long long nslots, long long nsum, double* __restrict__ sums,
                                                   int groups, const float* __restrict__ gamma, const float* __restrict__ beta, long long C,
                                                   double inv_count, float eps, float* __restrict__ table, long long st) {
@@ -67,17 +83,28 @@ __device__ __forceinline__ void gn_finalize_block(unsigned char* smem, const flo
             const float* sp = stats + (st * nslots) * npair + vec * 4;
             long long k = sl;
             for (; k + 3 * LANES < nsum; k += 4 * LANES) {          // (nsum <= nslots: the slots to add; nslots = the slot stride of a statistics group)
-                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
-                const float4 v1 = *reinterpret_cast<const float4*>(sp + (k + LANES) * npair);
-                const float4 v2 = *reinterpret_cast<const float4*>(sp + (k + 2 * LANES) * npair);
-                const float4 v3 = *reinterpret_cast<const float4*>(sp + (k + 3 * LANES) * npair);
+                float4 v0, v1, v2, v3;
+                if constexpr (COHERENT) {
+                    gn_ld4_coherent(sp + k * npair, sp + (k + LANES) * npair, sp + (k + 2 * LANES) * npair, sp + (k + 3 * LANES) * npair, v0, v1, v2, v3);
+                } else {
+                    v0 = *reinterpret_cast<const float4*>(sp + k * npair);
+                    v1 = *reinterpret_cast<const float4*>(sp + (k + LANES) * npair);
+                    v2 = *reinterpret_cast<const float4*>(sp + (k + 2 * LANES) * npair);
+                    v3 = *reinterpret_cast<const float4*>(sp + (k + 3 * LANES) * npair);
+                }
                 a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
                 a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
                 a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
                 a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
             }
             for (; k < nsum; k += LANES) {
-                const float4 v0 = *reinterpret_cast<const float4*>(sp + k * npair);
+                float4 v0;
+                if constexpr (COHERENT) {
+                    float4 u1, u2, u3;
+                    gn_ld4_coherent(sp + k * npair, sp + k * npair, sp + k * npair, sp + k * npair, v0, u1, u2, u3);
+                } else {
+                    v0 = *reinterpret_cast<const float4*>(sp + k * npair);
+                }
                 a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
             }
         }
@@ -222,22 +249,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
             }
         const long long slot = (img % imgs_per_stat) * gridDim.x + blockIdx.x;
         float* dst = stats + (((img / imgs_per_stat) * nslots + slot) * groups + tid) * 2;
-        dst[0] = a;
-        dst[1] = b;
+        if constexpr (FUSE) {
+            // write-through (sc0 sc1) and waited for: the slot is at the coherence point before this block takes its ticket - no fence: an
+            // agent-scope release fence writes back the whole L2 (the producing GEMM's output is still dirty in it), 25 us per launch measured
+            const f32x2_t v = {a, b};
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(v) : "memory");
+        } else {
+            dst[0] = a;
+            dst[1] = b;
+        }
     }
     if constexpr (FUSE) {
         __shared__ unsigned ticket;
         const long long st = img / imgs_per_stat;
         const unsigned writers = (unsigned)(gridDim.x * imgs_per_stat);        // blocks of this statistics group = slots it fills (slots 0 .. writers - 1)
-        __threadfence();                     // the slot stores above are visible device-wide before the ticket is taken (release)
-        __syncthreads();
-        if (tid == 0) ticket = __hip_atomic_fetch_add(fz.tickets + st, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                     // every slot store of the block has been waited for
+        if (tid == 0) ticket = __hip_atomic_fetch_add(fz.tickets + st, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (ticket != writers - 1) return;   // (block-uniform)
-        __threadfence();                     // acquire: the other blocks' slots
-        // the per-channel partials in gn_sh are dead (read above, barrier passed): the fold uses the same LDS
-        gn_finalize_block<256>(reinterpret_cast<unsigned char*>(gn_sh), stats, nslots, (long long)writers, nullptr, groups, fz.gamma, fz.beta, C, fz.inv_count, fz.eps,
-                               fz.table, st);
+        // the last block: every other block's slots were complete before its ticket; read them past the non-coherent cache levels.
+        // The per-channel partials in gn_sh are dead (read above, barrier passed): the fold uses the same LDS
+        gn_finalize_block<256, true>(reinterpret_cast<unsigned char*>(gn_sh), stats, nslots, (long long)writers, nullptr, groups, fz.gamma, fz.beta, C, fz.inv_count,
+                                     fz.eps, fz.table, st);
         if (tid == 0) __hip_atomic_store(fz.tickets + st, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
     }
 }
