@@ -531,6 +531,148 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(TP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Temporal self-attention on the matrix cores (round 5).  One wave per problem (sample b, position s, head h): T <= 32 frames, d_head 64.
+// The VALU kernel above spends ~2400 issue cycles per problem on dot2 arithmetic (46 us of vector ALU beside 75 us of HBM time at the 64 x 64
+// level, 2.8 TB/s measured); here the two contractions are 16 x 16 x 32 MFMAs on operands that need no repacking:
+//   S^T = K Q^T    A = K rows, B = Q rows: a lane (row = lane & 15, k-group g = lane >> 4) loads 16 bytes of frame `row` at channel
+//                  32 ks + 8 g - 64 contiguous bytes per frame per instruction, whole 128-byte lines over the two k steps, straight from HBM
+//                  into the operand registers (the frame stride of the channels-last layout is the row stride: no transpose, no staging).
+//                  Frames 16 .. 31 are the second row tile (T = 18: two live rows).  C: lane (query i = lane & 15, g) holds keys 4 g + r of
+//                  key tile jt - the softmax of a query is 8 register values x 4 lanes (two shuffle steps for the max and for the sum).
+//   O^T = V^T P^T  contraction slot 8 g + e  <->  key 16 (e >> 2) + 4 g + (e & 3): with THIS slot order the B operand of a lane is exactly the
+//                  eight probabilities it already holds (rounded to bf16 pairs), no lane exchange; the A operand V^T[d][slot] is gathered from
+//                  the wave's LDS copy of V (rows padded to 144 bytes: the four k-groups read four different 32-byte bank groups).
+//                  C: lane (query i, g) holds channels 16 dt + 4 g + r: an 8-byte store per (query tile, channel tile).
+// P is rounded to bf16 and the row is normalised by the sum of the ROUNDED weights, exactly as the VALU kernel (and the emulator) do.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(TP p) {
+    constexpr int VP = 72;                                  // LDS row pitch of V in bf16 (144 bytes)
+    __shared__ __attribute__((aligned(16))) bf16_t sVall[4][32 * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long pp = (long long)blockIdx.x * 4 + wave;
+    if (pp >= p.P) return;                                  // (wave-uniform; the LDS region is wave-private: no block barrier below)
+    bf16_t* sv = sVall[wave];
+    const int h = (int)(pp % p.heads);
+    const long long bs = pp / p.heads;
+    const long long s = bs % p.S, b = bs / p.S;
+    const int m = lane & 15, g = lane >> 4;
+    const int Tq = p.Tq, Tk = p.Tk;
+    const bf16_t* qb = p.q + b * p.q_sb + s * p.q_ss + h * 64;
+    const bf16_t* kb = p.k + b * p.kv_sb + s * p.kv_ss + h * 64;
+    const bf16_t* vb = p.v + b * p.kv_sb + s * p.kv_ss + h * 64;
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+
+    // ---- all global loads of the problem up front: V chunks (-> LDS), K and Q operand fragments
+    uint4 vch[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = u * 64 + lane;                        // chunk c: frame c >> 3, channels 8 (c & 7) ..
+        const int cc = c < Tk * 8 ? c : Tk * 8 - 1;         // (clamped, not predicated: a select between a load and zero became a select of POINTERS - flat loads from a zeroed scratch slot)
+        vch[u] = *reinterpret_cast<const uint4*>(vb + (long long)(cc >> 3) * p.kv_st + (cc & 7) * 8);
+    }
+    uint4 kf[2][2], qf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = 16 * t + m;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // rows past T are loaded from the last frame and zeroed in registers (keys past Tk are masked to -inf below; queries past Tq are never stored)
+            const uint4 ku = *reinterpret_cast<const uint4*>(kb + (long long)(row < Tk ? row : Tk - 1) * p.kv_st + ks * 32 + g * 8);
+            const uint4 qu = *reinterpret_cast<const uint4*>(qb + (long long)(row < Tq ? row : Tq - 1) * p.q_st + ks * 32 + g * 8);
+            kf[t][ks] = row < Tk ? ku : z4;
+            qf[t][ks] = row < Tq ? qu : z4;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = u * 64 + lane;
+        if (c < Tk * 8) *reinterpret_cast<uint4*>(sv + (c >> 3) * VP + (c & 7) * 8) = vch[u];
+    }
+
+    // ---- S^T = K Q^T
+    f32x4 sacc[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            sacc[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (jt * 16 < Tk && it * 16 < Tq) {             // (wave-uniform)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    sacc[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[jt][ks]), __builtin_bit_cast(bf16x8, qf[it][ks]),
+                                                                           sacc[jt][it], 0, 0, 0);
+            }
+        }
+
+    // ---- softmax over the keys of each query (lane & 15, query tile it): 8 values here, the other keys in the lanes +-16, +-32
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    uint4 pf[2];
+    float inv[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float v[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int key = 16 * (e >> 2) + 4 * g + (e & 3);
+            v[e] = key < Tk ? sacc[e >> 2][it][e & 3] * sl2 : -INFINITY;
+            mx = fmaxf(mx, v[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        uint32_t w[4];
+        float l = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(v[e] - mx), p1 = __builtin_amdgcn_exp2f(v[e + 1] - mx);
+            w[e >> 1] = pack2bf(p0, p1);
+            l += bflo(w[e >> 1]) + bfhi(w[e >> 1]);         // normalise by exactly the (rounded) weights that are applied
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        inv[it] = 1.0f / l;
+        pf[it] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+
+    // ---- O^T = V^T P^T: the wave's V rows are in LDS (written by other lanes of this wave: order the reads behind the writes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    f32x4 oacc[2][4];
+    const unsigned short* svu = reinterpret_cast<const unsigned short*>(sv);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        uint32_t a[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const int k0 = 16 * (e >> 2) + 4 * g + (e & 3);
+            const uint32_t lo = k0 < Tk ? (uint32_t)svu[k0 * VP + 16 * dt + m] : 0u;
+            const uint32_t hi = k0 + 1 < Tk ? (uint32_t)svu[(k0 + 1) * VP + 16 * dt + m] : 0u;
+            a[e >> 1] = lo | (hi << 16);
+        }
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(a[0], a[1], a[2], a[3]));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            oacc[it][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (it * 16 < Tq) oacc[it][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pf[it]), oacc[it][dt], 0, 0, 0);
+        }
+    }
+
+    // ---- out[query i][channels 16 dt + 4 g ..]: 8 bytes per (it, dt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 16 * it + m;
+        if (i < Tq) {
+            bf16_t* op = p.out + b * p.o_sb + (long long)i * p.o_st + s * p.o_ss + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<uint2*>(op + 16 * dt) = make_uint2(pack2bf(oacc[it][dt][0] * inv[it], oacc[it][dt][1] * inv[it]),
+                                                                     pack2bf(oacc[it][dt][2] * inv[it], oacc[it][dt][3] * inv[it]));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int v3d_attn_spatial(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vT, void* out,
@@ -579,6 +721,18 @@ extern "C" int v3d_attn_temporal(const void* q, int64_t q_sb, int64_t q_st, int6
     p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.kv_sb = kv_sb; p.kv_st = kv_st; p.kv_ss = kv_ss;
     p.out = (bf16_t*)out; p.o_sb = o_sb; p.o_st = o_st; p.o_ss = o_ss;
     p.P = (long long)B * S * heads; p.S = S; p.heads = heads; p.Tq = Tq; p.Tk = Tk; p.scale = scale;
+    static int timpl = -1;
+    if (timpl < 0) {
+        const char* e = getenv("V3D_ATTN_TEMPORAL_IMPL");   // A/B knob: 1 = the VALU (dot2) kernel of rounds 1-4, 2 = the MFMA kernel (default)
+        timpl = e ? atoi(e) : 2;
+    }
+    if (timpl != 1) {
+        p.G = 1;
+        const long long blocks = (p.P + 3) / 4;             // one wave per problem
+        V3D_REQUIRE(blocks < (1ll << 31), "v3d_attn_temporal: grid too large");
+        hipLaunchKernelGGL(attn_temporal_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        return v3d_check_launch("v3d_attn_temporal");
+    }
     {   // problems per wave: as many Tq-lane slots as fit in a wave, capped so K+V staging stays <= 16 KiB per wave
         int g = 64 / Tq;
         const int cap = 16384 / (Tk * 256);
