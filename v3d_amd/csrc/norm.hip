@@ -678,7 +678,15 @@ static int gn_small_groups(long long rows, long long C1, long long C2, int group
     if (groups != 32 || C % 32 || C1 % 8 || rows <= 0) return 0;
     const long long cpg = C / 32;
     if (cpg % 8) return 0;                                        // a 16-byte vector must lie inside one channel group
+    static int gb_max = -1;
+    if (gb_max < 0) {
+        const char* e = getenv("V3D_GN_SMALL_GB");                // tuning knob (tools/gn_small_bench.py): largest channel-group count per block
+        gb_max = e ? atoi(e) : 1;      // round 5 (profiles/r05_gn_small_gb.txt): the smallest slice with >= 64-byte row segments wins or ties everywhere
+                                       // (16 x 16 transformer norm 29.6 -> 20.0 us, two-source 8 x 8 norm 17.8 -> 12.5 us): more, shorter blocks
+        if (gb_max < 1) gb_max = 1;
+    }
     for (int gb = 8; gb >= 1; gb >>= 1) {
+        if (gb > gb_max && gb > 1 && (gb / 2) * cpg * 2 >= 64) continue;      // (a smaller slice still has row segments >= 64 bytes)
         if (C1 % (gb * cpg) && C2) continue;                      // a block's slice must lie inside one source
         if (rows * (gb * cpg / 8) <= 256 * 24 && gb * cpg * 2 >= 64) return gb;
     }
