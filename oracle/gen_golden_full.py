@@ -89,7 +89,7 @@ def main():
     out["frame_stats"] = torch.stack([frames.mean(dim=(1, 2, 3)), frames.std(dim=(1, 2, 3))], dim=1).clone()
     out["meta"] = {"threads": torch.get_num_threads(), "sampler_seconds": round(t_samp, 1), "decode_seconds": round(t_dec, 1),
                    "per_eval_seconds": state["times"], "sigmas": state["sigmas"],
-                   "frames_per_s": round(T / (t_samp + t_dec), 6), "torch": torch.__version__}
+                   "frames_per_s": round(T / (t_samp + t_dec), 6), "torch": str(torch.__version__)}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     torch.save(out, OUT)
     for k, v in out.items():

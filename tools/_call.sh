@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 300 python tools/lib_gemm_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05f_lib_gemm_probe.log
+( time timeout 900 python -m pytest tests/test_headline_parity_gpu.py -m gpu -q -k "reference_modules" --durations=8 ) > gpurun_out/r05h_pytest_refmodules.log 2>&1
+tail -30 gpurun_out/r05h_pytest_refmodules.log
+grep -E "parity\]" gpurun_out/r05h_pytest_refmodules.log | head
