@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( time timeout 900 python -m pytest tests/test_headline_parity_gpu.py -m gpu -q -k "reference_modules" --durations=8 ) > gpurun_out/r05h_pytest_refmodules.log 2>&1
-tail -30 gpurun_out/r05h_pytest_refmodules.log
-grep -E "parity\]" gpurun_out/r05h_pytest_refmodules.log | head
+timeout 300 python tools/attn_ab.py base=v3d_amd/lib/libv3d_hip.so noslp=v3d_amd/lib_exp/libv3d_attn_noslp.so defer=v3d_amd/lib_exp/libv3d_attn_defer.so defer_noslp=v3d_amd/lib_exp/libv3d_attn_defer_noslp.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05i_attn_ab.log

@@ -11,7 +11,7 @@ python -m v3d_amd.build > /dev/null 2>&1        # product objects up to date
 pids=""
 for f in $FILES; do
   b=${f%.hip}
-  x=""; [ "$f" = "ff.hip" ] && x="-fno-slp-vectorize"
+  x=""; { [ "$f" = "ff.hip" ] || [ "$f" = "attn.hip" ]; } && x="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-function -Wno-pass-failed $x $FLAGS -c $R/v3d_amd/csrc/$f -o $D/$b.o &
   pids="$pids $!"
 done

@@ -21,7 +21,9 @@ FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffast-math", 
          "-Wall", "-Wno-unused-function"]
 # ff.hip lays its instruction stream out by hand in fenced issue slots; the SLP vectoriser would pair up GELU pieces that belong to
 # different slots into v_pk_*_f32 (which also cost more than they save beside MFMAs)
-FILE_FLAGS = {"ff.hip": ["-fno-slp-vectorize"]}
+# attn.hip: the compiler SLP-packs the softmax's adjacent fp32 multiplies / adds into v_pk_*_f32, which beside MFMAs cost more than the scalar
+# pairs (same-process A/B, profiles/r05_attn_ab.txt: 917 -> 914 us alone, 895 -> 874 us together with the deferred maximum)
+FILE_FLAGS = {"ff.hip": ["-fno-slp-vectorize"], "attn.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

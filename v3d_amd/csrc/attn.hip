@@ -172,6 +172,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
 //   * one softmax update per 64-key tile (not per 32), O rescale skipped when no running max moved in the wave.
 // ------------------------------------------------------------------------------------------------------
 
+// round 5 (profiles/r05_attn_ab.txt, same-process A/B): deferred maximum + no SLP packing of the softmax arithmetic (v3d_amd/build.py FILE_FLAGS:
+// v_pk_mul_f32 / v_pk_add_f32 beside MFMAs cost more than the scalar pairs they replace) 917 -> 874 us at S = 4096, 133.6 -> 128.1 us at S = 1024
+#ifndef ATTN_DEFER_MAX
+#define ATTN_DEFER_MAX 8
+#endif
+
 template <int QG>
 __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* __restrict__ q, long long ldq,
                                                                  const bf16_t* __restrict__ k, long long ldk,
@@ -310,7 +316,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[g][sub][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[g], mx);          // raw-score domain; every tile holds >= 1 valid key, so finite
+            float m_new = fmaxf(m_run[g], mx);                // raw-score domain; every tile holds >= 1 valid key, so finite
+            // deferred maximum (ATTN_DEFER_MAX > 0): a running maximum that grew by less than 2^ATTN_DEFER_MAX keeps its old value - the
+            // tile's weights are then at most 2^ATTN_DEFER_MAX (exact in fp32 / bf16 alike: the format is scale-free) and alpha = 1, so the
+            // 128-multiply rescale of O^T below, which some lane of a 128-query wave triggers on almost every one of the 64 tiles at
+            // S = 4096, runs only while the first tiles settle.  O / l is the same quotient either way.  (-inf start: the difference is +inf)
+            if (ATTN_DEFER_MAX > 0 && (m_new - m_run[g]) * scale2 <= (float)ATTN_DEFER_MAX) m_new = m_run[g];
             alpha[g] = __builtin_amdgcn_exp2f((m_run[g] - m_new) * scale2);   // first tile: exp2(-inf) = 0 on o = l = 0
             any_rescale |= (alpha[g] != 1.f);
             const float mb = -m_new * scale2;
