@@ -1,4 +1,6 @@
-"""TEST INFRASTRUCTURE — fp32 CPU restatement of the reference's algorithm for the V3D hot path.
+"""TEST INFRASTRUCTURE — fp32 restatement of the reference's algorithm for the V3D hot path (device-agnostic functional torch: it
+runs where its input tensors live - on the CPU in the -m "not gpu" tests and in bench.py's cpu_baseline, on the GPU in fp32 as the
+checker of the full-width -m gpu tests, tests/conftest.py::device_oracle).
 
 A functional, state-dict-driven torch restatement (NCHW, fp32, no autocast) of
     EulerEDMSampler -> LinearPredictionGuider -> Denoiser(VScalingWithEDMcNoise) -> OpenAIWrapper -> VideoUNet

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 300 python tools/attn_ab.py base=v3d_amd/lib/libv3d_hip.so noslp=v3d_amd/lib_exp/libv3d_attn_noslp.so defer=v3d_amd/lib_exp/libv3d_attn_defer.so defer_noslp=v3d_amd/lib_exp/libv3d_attn_defer_noslp.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05i_attn_ab.log
+timeout 500 python tools/mainloop_ab.py base=v3d_amd/lib/libv3d_hip.so noslp=v3d_amd/lib_exp/libv3d_gc_noslp.so --rounds=5 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05j_gemm_conv_noslp_ab.log
