@@ -210,6 +210,8 @@ class _Timed:
         self._wrap("attn_spatial", m_attn)
         self._wrap("attn_temporal", m_tattn)
         self._wrap("groupnorm_stats", m_gns)
+        if hasattr(self.ops, "groupnorm_stats_table"):      # ABI 5: statistics + table in one launch (same kernel family, same bytes: the tensor once)
+            self._wrap("groupnorm_stats_table", lambda x1, x2, stats, tickets, n_img, S, groups, ips, *a: m_gns(x1, x2, stats, n_img, S, groups, ips))
         self._wrap("groupnorm_apply", m_gna)
         self._wrap("groupnorm_finalize", m_gnf)
         self._wrap("layernorm", m_ln)

@@ -31,6 +31,8 @@ def gk(g):
     return f"gemm m{g.mode} M={g.M} N={g.N} K={g.K} b={g.batch} [{ep}]", 2.0 * g.M * g.N * g.K * taps * g.batch
 wrap("gemm", gk)
 wrap("groupnorm_stats", lambda x1, x2, st, n, S, g, ips: (f"gn_stats n={n} S={S} C={x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)} ips={ips}", 0))
+if hasattr(ops, "groupnorm_stats_table"):
+    wrap("groupnorm_stats_table", lambda x1, x2, st, tk, n, S, g, ips, *a: (f"gn_stats+table n={n} S={S} C={x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)} ips={ips}", 0))
 wrap("groupnorm_apply", lambda x1, x2, *a: (f"gn_apply rows={x1.shape[0]} C={x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)}", 0))
 wrap("groupnorm_finalize", lambda st, sums, *a: (f"gn_finalize n_stat={st.shape[0]} slots={st.shape[1]}", 0))
 for nm in ("ff_fused", "ln_ff_fused", "ln_proj"):
