@@ -1,3 +1,8 @@
+// LAB RECORD, NOT PRODUCT CODE (round 5: moved out of v3d_amd/csrc; linked only into the experiments library, `python -m v3d_amd.build --experiments`,
+// and selected there with V3D_GEMM_V4=1).  Bit-equal to v3 and 5 % slower (NOTES 11.2).  Its literal-AGPR accumulators are protected by nothing but
+// register pressure: the AGPR audit script its comments cite (tools/check_agpr.py) was never committed - do not promote this file into
+// the product library without one.
+//
 // v4: persistent 4-wave kernels of the v3d_gemm family - ONE wave per SIMD, software-pipelined inside the wave (gfx950).
 //
 // Why (round 4; profiles/r04_mainloop_ab.txt, r04_sq_counters.txt): the v3 kernels run two wave groups per SIMD half a step apart - a wave is
