@@ -35,6 +35,10 @@ def tiny_unet_inputs(T: int, H: int, W: int, seed: int):
     return noise, c, uc, x8, timesteps, context, y
 
 
+def ctx5_tokens(T: int, seed: int):
+    return torch.randn(2 * T, 5, 1024, generator=torch.Generator().manual_seed(seed + 5))
+
+
 @torch.no_grad()
 def main():
     torch.set_grad_enabled(False)
@@ -54,6 +58,10 @@ def main():
     ioi1 = ioi0.clone()
     ioi1[1, 1] = 1.0
     out["unet_out_ioi"] = net(x8, timesteps, context=context, y=y, num_video_frames=T, image_only_indicator=ioi1).clone()
+
+    # ---- general cross-attention: a context of 5 tokens per image (attention.py:286-349 without the one-token shortcut every V3D / SVD
+    #      configuration takes; round 5).  Tokens differ per image, so the temporal block's frame-0 context (video_attention.py:249-253) shows.
+    out["unet_out_ctx5"] = net(x8, timesteps, context=ctx5_tokens(T, p["seed"]), y=y, num_video_frames=T, image_only_indicator=ioi0).clone()
 
     # ---- one VideoResBlock / one SpatialVideoTransformer in isolation (block-level pins) ----
     g = torch.Generator().manual_seed(p["seed"] + 2)

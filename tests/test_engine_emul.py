@@ -8,7 +8,7 @@ import torch
 
 from conftest import rel_cos
 from oracle.ops_emul import EmulOps
-from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs
+from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, ctx5_tokens, decoder_latents, tiny_unet_inputs
 from v3d_amd.ops import use_backend
 from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
@@ -30,6 +30,27 @@ def test_unet(golden, exact, tol, cosmin):
         assert rel <= tol and cos >= cosmin, (rel, cos)
         ioi[1, 1] = 1.0
         rel, cos = rel_cos(net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=ioi), golden["unet_out_ioi"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)
+
+
+@pytest.mark.parametrize("exact,tol,cosmin", MODES)
+def test_unet_multi_token_context(golden, exact, tol, cosmin):
+    """A context of 5 tokens per image takes the engine's general cross-attention path (engine/unet.py cross_attention: LayerNorm, to_q, to_k | to_v on
+    the tokens, v3d_attn_temporal's problem shape with 32-row query blocks and a zero key stride, to_out + residual) instead of the one-token
+    collapse - against the fixture the reference's own modules produced; one token per image must still take the collapsed path bit for bit."""
+    p = TINY
+    T = p["T"]
+    _, _, _, x8, ts, ctx, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    with use_backend(EmulOps("cpu", exact=exact)):
+        net = build_unet()
+        ioi = torch.zeros(2, T)
+        out = net(x8, ts, context=ctx5_tokens(T, p["seed"]), y=y, num_video_frames=T, image_only_indicator=ioi)
+        rel, cos = rel_cos(out, golden["unet_out_ctx5"])
+        assert rel <= tol and cos >= cosmin, (rel, cos)
+        assert (out - golden["unet_out"]).abs().max() > 1e-2           # (another context: another output)
+        # the same token five times == that one token (softmax over identical keys): the general path against the collapsed one
+        rep = net(x8, ts, context=ctx.repeat(1, 5, 1), y=y, num_video_frames=T, image_only_indicator=ioi)
+        rel, cos = rel_cos(rep, golden["unet_out"])
         assert rel <= tol and cos >= cosmin, (rel, cos)
 
 
@@ -136,15 +157,16 @@ def test_load_last_embedder_is_refused():
         instantiate_from_config(cfg)
 
 
-def test_unet_rejects_multi_token_context_and_missing_indicator():
-    """The collapsed cross-attention is exact for one context token only; learned_with_images needs the indicator (util.py:352-354)."""
+def test_unet_rejects_oversized_context_and_missing_indicator():
+    """Contexts of 1 .. 32 tokens per image are served (one: the collapsed path; more: the general cross-attention, round 5) - anything longer is
+    refused loudly, not truncated; learned_with_images needs the indicator (util.py:352-354)."""
     p = TINY
     T = p["T"]
     _, _, _, x8, ts, ctx, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
     with use_backend(EmulOps("cpu", exact=True)):
         net = build_unet()
-        with pytest.raises(AssertionError, match="one token per image"):
-            net(x8, ts, context=torch.cat([ctx, ctx], dim=1), y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
+        with pytest.raises(AssertionError, match="1 <= N <= 32 tokens"):
+            net(x8, ts, context=ctx.repeat(1, 33, 1), y=y, num_video_frames=T, image_only_indicator=torch.zeros(2, T))
         with pytest.raises(AssertionError, match="image_only_indicator is required"):
             net(x8, ts, context=ctx, y=y, num_video_frames=T, image_only_indicator=None)
 

@@ -7,7 +7,7 @@ from conftest import record_parity
 import torch
 
 from conftest import device_oracle, odev, rel_cos, full_inputs as _full_inputs  # noqa: F401  (`full_unet` is the session fixture of conftest.py)
-from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, decoder_latents, tiny_unet_inputs, to_dev
+from tiny import SAMPLER_FIXTURES, TINY, build_decoder, build_denoiser, build_sampler, build_unet, ctx5_tokens, decoder_latents, tiny_unet_inputs, to_dev
 from v3d_amd.sgm.modules.diffusionmodules.wrappers import OpenAIWrapper
 
 pytestmark = pytest.mark.gpu
@@ -33,6 +33,30 @@ def test_unet_vs_reference_fixture(golden):
     ioi[1, 1] = 1.0
     out = net(x8.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi)
     rel, cos = rel_cos(out, golden["unet_out_ioi"])
+    assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
+
+
+@pytest.mark.parametrize("n_ctx", [5, 32])
+def test_unet_multi_token_context(golden, n_ctx):
+    """General cross-attention on the HIP kernels (contexts of 2 .. 32 tokens; every V3D / SVD configuration conditions on one): 5 tokens per image
+    against the fixture of the reference's own modules, 32 (the kernel's limit, both key tiles full) against the fp32 oracle."""
+    from oracle import sgm_oracle as O
+    from v3d_amd import synth
+    p = TINY
+    T = p["T"]
+    _, _, _, x8, ts, _, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    net = build_unet(DEV)
+    ioi = torch.zeros(2, T, device=DEV)
+    if n_ctx == 5:
+        ctx = ctx5_tokens(T, p["seed"])
+        ref = golden["unet_out_ctx5"]
+    else:
+        ctx = torch.randn(2 * T, n_ctx, 1024, generator=torch.Generator().manual_seed(77))
+        with device_oracle() as od:
+            ref = O.unet_forward(odev(net.state_dict(), od), synth.unet_config(p["model_channels"]), *odev((x8, ts, ctx, y), od), T, torch.zeros(2, T, device=od)).cpu()
+    out = net(x8.to(DEV), ts.to(DEV), context=ctx.to(DEV), y=y.to(DEV), num_video_frames=T, image_only_indicator=ioi)
+    rel, cos = rel_cos(out, ref)
+    record_parity(f"unet_eval_context_{n_ctx}_tokens", {"max_rel_err": round(rel, 5), "cosine": round(cos, 6)})
     assert rel <= 4e-2 and cos >= 0.999, (rel, cos)
 
 

@@ -3,7 +3,7 @@ reference's own modules (oracle/gen_golden.py).  fp32 restatement vs reference: 
 import torch
 
 from oracle import sgm_oracle as O
-from tiny import TINY, decoder_latents, tiny_unet_inputs
+from tiny import TINY, ctx5_tokens, decoder_latents, tiny_unet_inputs
 from v3d_amd import synth
 from v3d_amd.sgm.modules.autoencoding.temporal_ae import VideoDecoder
 from v3d_amd.sgm.modules.diffusionmodules.video_model import VideoUNet
@@ -29,6 +29,16 @@ def test_unet_eval_and_ioi(golden):
     _close(O.unet_forward(sd, cfg, x8, ts, ctx, y, T, ioi), golden["unet_out"])
     ioi[1, 1] = 1.0
     _close(O.unet_forward(sd, cfg, x8, ts, ctx, y, T, ioi), golden["unet_out_ioi"])
+
+
+def test_unet_eval_multi_token_context(golden):
+    """General cross-attention (a context of 5 tokens per image, different per image): attention.py:286-349 without the one-token case every
+    V3D / SVD configuration takes, and the temporal block's frame-0 context (video_attention.py:249-253)."""
+    p = TINY
+    T = p["T"]
+    sd, cfg = _unet_sd(), synth.unet_config(p["model_channels"])
+    _, _, _, x8, ts, _, y = tiny_unet_inputs(T, p["H"], p["W"], p["seed"])
+    _close(O.unet_forward(sd, cfg, x8, ts, ctx5_tokens(T, p["seed"]), y, T, torch.zeros(2, T)), golden["unet_out_ctx5"])
 
 
 def test_blocks(golden):

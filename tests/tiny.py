@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from oracle.gen_golden import TINY, tiny_unet_inputs  # noqa: F401  (seeds / shapes of the committed fixtures)
+from oracle.gen_golden import TINY, ctx5_tokens, tiny_unet_inputs  # noqa: F401  (seeds / shapes of the committed fixtures)
 from v3d_amd import synth
 
 P = "v3d_amd.sgm.modules.diffusionmodules."

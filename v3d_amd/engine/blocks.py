@@ -38,6 +38,10 @@ class Env:
     ctx_all: Optional[torch.Tensor] = None     # fp32 [n, ctx_ld]: every block's collapsed 1-token cross-attention
     coefs: Optional[torch.Tensor] = None       # fp32 [n_mixers, n, 3]: AlphaBlender epilogue coefficients
     shard: Optional[object] = None             # v3d_amd.dist.FrameShard when the frame axis is sharded over ranks
+    # contexts of more than one token (general cross-attention; V3D / SVD condition on ONE token and use ctx_all instead):
+    ctx_tok: Optional[torch.Tensor] = None     # bf16 [n * N, ctx_dim]: every image's N context tokens
+    ctx0_tok: Optional[torch.Tensor] = None    # bf16 [B * N, ctx_dim]: frame-0 context of each sample (the temporal block's context)
+    n_ctx: int = 1
 
 
 # GroupNorm statistics gathered by the GEMM that produces the tensor (GemmCall.gn_stats: the v3 <GN> epilogue, or the stand-alone pass inside

@@ -223,6 +223,13 @@ class SVTPack:
     t_wqkv_fused: Optional[tuple] = None
     t_wo: tuple = None
     t_ctx_off: int = 0
+    # general cross-attention (context of 2 .. 32 tokens: attention.py:286-349 without the one-token collapse): module references, packed on
+    # first use by cross_attn_pack (every V3D / SVD configuration conditions on ONE token and never builds these)
+    s_attn2: object = None
+    s_norm2: object = None
+    t_attn2: object = None
+    t_norm2: object = None
+    x2: Dict = field(default_factory=dict)       # "s" / "t" -> (norm2, wq, wkv, wo, bo)
     t_norm3: tuple = None
     t_ff: FFPack = None
     tpe: tuple = None                # time_pos_embed (w0, b0, w2, b2)
@@ -340,6 +347,7 @@ def pack_svt(st, col: _Collector) -> SVTPack:
         p.t_wqkv_fused = ln_proj_pack(torch.cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dim=0), tb.norm1.weight, tb.norm1.bias)
     p.s_wo = pack_linear(blk.attn1.to_out[0])
     p.s_ctx_off = col.add_ctx(blk.attn2)
+    p.s_attn2, p.s_norm2 = blk.attn2, blk.norm2
     p.s_norm3 = pack_norm(blk.norm3)
     p.s_ff = _pack_ff(blk.ff, blk.norm3)
     assert tb.ff_in is not False and tb.is_res
@@ -350,12 +358,24 @@ def pack_svt(st, col: _Collector) -> SVTPack:
     p.t_wo = pack_linear(tb.attn1.to_out[0])
     assert tb.attn2 is not None, "disable_temporal_crossattention is not used by V3D/SVD"
     p.t_ctx_off = col.add_ctx(tb.attn2)
+    p.t_attn2, p.t_norm2 = tb.attn2, tb.norm2
     p.t_norm3 = pack_norm(tb.norm3)
     p.t_ff = _pack_ff(tb.ff, tb.norm3)
     p.tpe = pack_linear(st.time_pos_embed[0]) + pack_linear(st.time_pos_embed[2])
     p.max_period = float(st.max_time_embed_period)
     p.mixer = col.add_mixer(st.time_mixer, 1)
     return p
+
+
+def cross_attn_pack(p: SVTPack, which: str):
+    """(norm2, W_q [C, C], W_k | W_v [2C, ctx_dim], W_o [C, C], b_o) of the spatial ("s") / temporal ("t") attn2 of a transformer block, for contexts of
+    more than one token (CrossAttention.forward, attention.py:286-349: to_q / to_k / to_v without bias, to_out[0] with bias).  Packed on first use."""
+    if which not in p.x2:
+        attn, norm = (p.s_attn2, p.s_norm2) if which == "s" else (p.t_attn2, p.t_norm2)
+        wq = _bf(attn.to_q.weight)
+        wkv = _bf(torch.cat([attn.to_k.weight.detach(), attn.to_v.weight.detach()], dim=0))
+        p.x2[which] = (pack_norm(norm), wq, wkv) + pack_linear(attn.to_out[0])
+    return p.x2[which]
 
 
 def pack_unet(net) -> UNetPack:

@@ -20,7 +20,7 @@ import torch
 
 from ..ops import GemmCall, get_ops
 from .blocks import Env, Geo, unet_resblock
-from .packing import SVTPack, UNetPack, round_up
+from .packing import SVTPack, UNetPack, cross_attn_pack, round_up
 
 BF, F32 = torch.bfloat16, torch.float32
 
@@ -47,11 +47,35 @@ def frame_pos_table(ops, p: SVTPack, B: int, frame_ids) -> torch.Tensor:
     return tab
 
 
+def cross_attention(ops, x: torch.Tensor, pack, ctx_rows: torch.Tensor, n_ctx: int, heads: int) -> torch.Tensor:
+    """x + attn2(norm2(x), context) for a context of 2 .. 32 tokens (BasicTransformerBlock / VideoTransformerBlock, attention.py:565-571,
+    video_attention.py:127-133; CrossAttention.forward attention.py:286-349).  x [M, C] rows; ctx_rows [G * n_ctx, ctx_dim]: G contexts, each shared
+    by M / G consecutive rows (one image of the spatial block; one whole sample - T frames - of the temporal block, whose context is the sample's
+    frame-0 context).  The attention is v3d_attn_temporal's problem shape with other strides: up to 32 consecutive query rows x n_ctx keys x d_head 64 per
+    (context, row block, head) - the matrix-core kernel of round 5 takes Tq != Tk and a zero key stride across row blocks as they come."""
+    M, C = x.shape
+    (ga, be, eps), wq, wkv, wo, bo = pack
+    G = ctx_rows.shape[0] // n_ctx
+    R = M // G
+    assert G * R == M and 2 <= n_ctx <= 32, f"cross-attention: {M} rows / {G} contexts of {n_ctx} tokens (2..32 tokens)"
+    QB = max(d for d in range(1, 33) if R % d == 0)                   # query rows per problem: the largest divisor of a context's row count <= 32
+    n2 = ops.empty((M, C), ops.act_dtype, x.device)
+    ops.layernorm(x, ga, be, n2, eps)
+    q = ops.linear(n2, wq)
+    kv = ops.linear(ctx_rows, wkv)                                    # [G * n_ctx, 2C]: k | v of every context token
+    a = ops.empty((M, C), ops.act_dtype, x.device)
+    blk = lambda t: t.view(G, R // QB, QB, C).permute(0, 2, 1, 3)     # [G, QB query rows, row blocks, C]
+    tok = lambda t: t.view(G, n_ctx, 1, C).expand(G, n_ctx, R // QB, C)   # the same n_ctx keys for every row block: stride 0
+    ops.attn_temporal(blk(q), tok(kv[:, :C]), tok(kv[:, C:]), blk(a), heads, 0.125)
+    return ops.linear(a, wo, bo, res1=x)
+
+
 def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
     ops = env.ops
     n, S, C, T, B = g.n, g.S, p.C, g.T, g.B
     sh = env.shard
-    ctx, ctx_ld = env.ctx_all, env.ctx_all.stride(0)
+    ctx = env.ctx_all
+    ctx_ld = ctx.stride(0) if ctx is not None else 0
 
     ga, be, eps = p.norm
     h = ops.groupnorm(x_in, None, ga, be, n, S, eps=eps, silu=False)
@@ -80,8 +104,13 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
         ops.attn_spatial_fp8(qk8, qk_scales, v8, v_scale, a, n, S, p.heads, 0.125)
     else:
         ops.attn_spatial(qk[:, :C], qk[:, C:], vT, a, n, S, p.heads, 0.125)
-    # x = attn1 + x, then attn2 (1 context token => a per-image vector, Appendix B-9) folded in the same epilogue
-    x = ops.linear(a, p.s_wo[0], p.s_wo[1], res1=x, add=ctx[:, p.s_ctx_off:], add_rpg=S, add_ld=ctx_ld)
+    multi = env.ctx_tok is not None                  # context of more than one token: the general cross-attention (no V3D / SVD config)
+    if multi:
+        x = ops.linear(a, p.s_wo[0], p.s_wo[1], res1=x)
+        x = cross_attention(ops, x, cross_attn_pack(p, "s"), env.ctx_tok, env.n_ctx, p.heads)
+    else:
+        # x = attn1 + x, then attn2 (1 context token => a per-image vector, Appendix B-9) folded in the same epilogue
+        x = ops.linear(a, p.s_wo[0], p.s_wo[1], res1=x, add=ctx[:, p.s_ctx_off:], add_rpg=S, add_ld=ctx_ld)
     # norm3 + ff: at the 64x64 level the LayerNorm runs inside the fused feed-forward (v3d_ln_ff_fused), else as its own launch
     x_s = feed_forward(ops, x, p.s_ff, res1=x, ln=p.s_norm3)
 
@@ -115,8 +144,12 @@ def run_svt(env: Env, g: Geo, p: SVTPack, x_in: torch.Tensor) -> torch.Tensor:
         ops.attn_temporal(q, kv[..., :C], kv[..., C:], ta, p.heads, 0.125)
     # temporal attn2: context = frame-0 context of each sample (video_attention.py:249-253) -> per-sample vector
     # (rows n.. of ctx_all hold the frame-0 projections, one per sample)
-    x_t = ops.linear(ta.view(n * S, C), p.t_wo[0], p.t_wo[1], res1=x_t, add=ctx[n:, p.t_ctx_off:], add_rpg=S * T,
-                     add_ld=ctx_ld)
+    if multi:
+        x_t = ops.linear(ta.view(n * S, C), p.t_wo[0], p.t_wo[1], res1=x_t)
+        x_t = cross_attention(ops, x_t, cross_attn_pack(p, "t"), env.ctx0_tok, env.n_ctx, p.heads)
+    else:
+        x_t = ops.linear(ta.view(n * S, C), p.t_wo[0], p.t_wo[1], res1=x_t, add=ctx[n:, p.t_ctx_off:], add_rpg=S * T,
+                         add_ld=ctx_ld)
     # AlphaBlender fused: alpha * x_s + (1 - alpha) * (ff(norm3(x_t)) + x_t)
     x = feed_forward(ops, x_t, p.t_ff, res1=x_t, res2=x_s, coef=env.coefs[p.mixer], coef_rpg=S, ln=p.t_norm3)
     return ops.linear(x, p.proj_out[0], p.proj_out[1], res1=x_in)
@@ -185,13 +218,22 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
         lab = ops.linear(ops.silu_add(ops.linear(yb, w0, b0, out_dtype=F32)), w2, b2, out_dtype=F32)
     semb = ops.silu_add(e, lab)                                             # SiLU(emb): input of every emb_layers
     emb_all = ops.linear(semb, pk.emb_w, pk.emb_b, out_dtype=F32)           # [n, sum Cout]
-    # the collapsed cross-attention (W_ov folded at pack time, engine/packing.py) is exact for ONE context token only
-    assert context is not None and context.dim() == 3 and context.shape[0] == n and context.shape[1] == 1, \
-        f"context must be [n={n}, 1, context_dim] (one token per image, as V3D / SVD condition), got {None if context is None else tuple(context.shape)}"
-    c2 = context.reshape(n, -1)
-    c0 = c2[::T] if context_frame0 is None else context_frame0.reshape(B, -1)   # time_context = context[::timesteps]
-    cb = _cast_rows_bf16(ops, torch.cat([c2, c0.to(c2.dtype)], dim=0))
-    ctx_all = ops.linear(cb, pk.ctx_w, pk.ctx_b, out_dtype=F32)            # [n + B, sum C]
+    assert context is not None and context.dim() == 3 and context.shape[0] == n and 1 <= context.shape[1] <= 32, \
+        f"context must be [n={n}, N, context_dim] with 1 <= N <= 32 tokens per image (V3D / SVD condition on one), got {None if context is None else tuple(context.shape)}"
+    n_ctx = context.shape[1]
+    ctx_all = ctx_tok = ctx0_tok = None
+    if n_ctx == 1:
+        # the collapsed cross-attention (W_ov folded at pack time, engine/packing.py) is exact for ONE context token only
+        c2 = context.reshape(n, -1)
+        c0 = c2[::T] if context_frame0 is None else context_frame0.reshape(B, -1)   # time_context = context[::timesteps]
+        cb = _cast_rows_bf16(ops, torch.cat([c2, c0.to(c2.dtype)], dim=0))
+        ctx_all = ops.linear(cb, pk.ctx_w, pk.ctx_b, out_dtype=F32)            # [n + B, sum C]
+    else:
+        # general cross-attention: the tokens themselves go to every block (engine cross_attention); time_context = context[::timesteps]
+        assert shard is None, "frame-sharded evaluation supports one context token per image"
+        c0 = context[::T] if context_frame0 is None else context_frame0.reshape(B, n_ctx, -1)
+        both = _cast_rows_bf16(ops, torch.cat([context.reshape(n * n_ctx, -1), c0.reshape(B * n_ctx, -1).to(context.dtype)], dim=0))
+        ctx_tok, ctx0_tok = both[:n * n_ctx], both[n * n_ctx:]
     ioi = None
     # merge_strategy="learned_with_images" needs the indicator (AlphaBlender.get_alpha asserts it, util.py:352-354)
     assert not pk.uses_ioi or image_only_indicator is not None, "image_only_indicator is required by merge_strategy='learned_with_images'"
@@ -202,7 +244,7 @@ def run_unet(pk: UNetPack, x, scale, concat, timesteps, context, y, num_video_fr
         ioi = ioi.reshape(-1).float().contiguous()
         assert ioi.numel() == n, f"image_only_indicator has {ioi.numel()} entries for {n} images"
     coefs = ops.blend_coefs(pk.mix_alpha, pk.mix_kind, ioi, n)
-    env = Env(ops=ops, emb_all=emb_all, ctx_all=ctx_all, coefs=coefs, shard=shard)
+    env = Env(ops=ops, emb_all=emb_all, ctx_all=ctx_all, coefs=coefs, shard=shard, ctx_tok=ctx_tok, ctx0_tok=ctx0_tok, n_ctx=n_ctx)
 
     # first convolution (8 input channels): the packed input leaves its assembly kernel already unfolded 3x3 and the convolution is ONE GEMM
     # with K = 96 (per tap K = 8 is below every MFMA kernel's granule: the implicit-GEMM launch ran on the generic kernel, 258 us)
