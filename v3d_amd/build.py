@@ -93,7 +93,28 @@ def _build(force, verbose, LIBDIR, libname, extra) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if not extra:
+        build_comm(force=force, verbose=verbose)
     return LIB
+
+
+COMM_SRC = os.path.join(HERE, "csrc_comm", "comm.hip")
+COMM_LIB = os.path.join(LIBDIR, "libv3d_comm.so")
+
+
+def build_comm(force: bool = False, verbose: bool = True) -> str:
+    """libv3d_comm.so (include/v3d_comm.h): the RCCL wrappers of the frame-axis exchanges for hosts without torch.distributed - its own
+    library (links librccl; the kernel library does not)."""
+    hdr = os.path.join(os.path.dirname(HERE), "include", "v3d_comm.h")
+    if force or _stale(COMM_LIB, [COMM_SRC, hdr]):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
+        cmd = [_hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", COMM_SRC, "-o", COMM_LIB, f"-L{rocm_lib}", "-lrccl"]
+        if verbose:
+            print("[v3d_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {COMM_SRC}:\n{r.stdout}\n{r.stderr}")
+    return COMM_LIB
 
 
 if __name__ == "__main__":
