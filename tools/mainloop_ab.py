@@ -105,6 +105,12 @@ def build_cases(hip0, only):
     lin("geglu_L1", 36 * 1024, 5120, 640, geglu=True)
     lin("geglu_L2", 36 * 256, 10240, 1280, geglu=True)
     lin("lin_sq_4096", 4096, 4096, 4096)
+    # the plain q | k | v projection shapes of the vendor-library probe (library 1022-1054 TF/s)
+    lin("plain_9216_2560_1280", 9216, 2560, 1280, bias=False)
+    lin("plain_9216_3840_1280", 9216, 3840, 1280, bias=False)
+    lin("plain_36864_1280_640", 36864, 1280, 640, bias=False)
+    lin("plain_36864_1280_640_br", 36864, 1280, 640, res=True)
+    lin("plain_sq_8192", 8192, 8192, 8192, bias=False)
     return cases
 
 

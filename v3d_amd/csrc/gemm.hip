@@ -920,6 +920,13 @@ int dispatch(const GP& p, int batch, hipStream_t st) {
                     const char* e = getenv("V3D_GEMM_V4");
                     v4 = e ? atoi(e) : 0;
                 }
+                static int v5 = -1;
+                if (v5 < 0) {
+                    const char* e = getenv("V3D_GEMM_V5");
+                    v5 = e ? atoi(e) : 0;
+                }
+                const int v5v = v5 ? v3d_gemm_v5_variant(p, MODE, variant) : 0;
+                if (v5v) return v3d_gemm_v5_launch(p, MODE, v5v, (void*)st);
                 const int v4v = v4 ? v3d_gemm_v4_variant(p, MODE, variant) : 0;
                 if (v4v) {
                     if (p.gn_stats) {

@@ -77,6 +77,9 @@ int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream);
 // variant: 1 = 192 x 320 tiles, 2 = 256 x 256).  5 % slower than v3 (NOTES 11.2): kept as a lab record, not part of the product library.
 int v3d_gemm_v4_variant(const V3dGemmParams& p, int mode, int v3_variant);
 int v3d_gemm_v4_launch(const V3dGemmParams& p, int mode, int variant, void* stream);
+// tools/lab/gemm5.hip: the same structure on v_mfma_f32_32x32x16_bf16 (round 6, V3D_GEMM_V5=1)
+int v3d_gemm_v5_variant(const V3dGemmParams& p, int mode, int v3_variant);
+int v3d_gemm_v5_launch(const V3dGemmParams& p, int mode, int variant, void* stream);
 #endif
 // gemm.hip: stream-K plan of a persistent launch (fills p.sk_*, returns the grid): ntiles tiles of `units` split granules on the device's CUs;
 // slot_bytes = one block's accumulators in fp32.  Leaves the classic assignment (sk_tail = 0) when the tail round is full enough or too thin.
