@@ -4,7 +4,10 @@ Reference call sites: sgm/modules/encoders/modules.py:594-752 (FrozenOpenCLIPIma
 (224, bicubic, align_corners=True, antialias) -> (x+1)/2 -> kornia.enhance.normalize(mean, std); then `self.model.visual(img)`),
 modules.py:1054-1072 (FrozenOpenCLIPImagePredictionEmbedder), scripts/pub/V3D_512.py:146-153,238.
 
-PARITY UNPINNED.  The arithmetic lives in two third-party packages that are absent from /root/reference and from this image:
+PARITY: the ViT TOWER is pinned (round 6) - tests/golden/clip_tower.pt holds `image_embeds` of transformers' CLIPVisionModelWithProjection (an
+independent implementation of the same architecture, importable in this image) on seeded weights, reduced depth and full ViT-H/14
+(oracle/gen_golden_clip.py; restatement vs transformers: max abs diff ~1e-6).  The kornia resize in front of it remains RESTATED, unpinned.
+The arithmetic lives in two third-party packages that are absent from /root/reference and from this image:
   * open_clip (`open-clip-torch`, requirements.txt, un-pinned): `VisionTransformer.forward` of model ViT-H-14 - conv1 (patch 14,
     no bias), class token + positional embedding, ln_pre, 32 x ResidualAttentionBlock {x + nn.MultiheadAttention(ln_1 x);
     x + c_proj(GELU(c_fc(ln_2 x)))}, ln_post on the class token, @ proj (1280 -> 1024); restated below from its published source
@@ -12,8 +15,8 @@ PARITY UNPINNED.  The arithmetic lives in two third-party packages that are abse
   * kornia (`kornia==0.6.9`, requirements.txt): `geometry.transform.resize` - when down-scaling and antialias: gaussian_blur2d with
     sigma = max((factor - 1) / 2, 0.001) per axis, kernel int(max(4 sigma, 3)) made odd, border "reflect"; then
     F.interpolate(mode="bicubic", align_corners=True).
-Neither can be imported to generate fixtures, and the reference has no test for this path; the restatement is anchored on the
-reference's call sites and on the checkpoint key names only.
+Neither can be imported, and the reference has no test for this path; the resize restatement is anchored on the reference's call sites and
+kornia's published source only.
 """
 from collections import OrderedDict
 
@@ -89,6 +92,31 @@ class VisionTransformer(nn.Module):
         x = x.permute(1, 0, 2)
         pooled = self.ln_post(x[:, 0])
         return pooled @ self.proj
+
+
+def seeded_visual_state_dict(vision_cfg, seed):
+    """A reproducible open_clip-named state dict of the visual tower (plain CPU torch.Generator draws in key order): what oracle/gen_golden_clip.py
+    fed the independent implementation, and what the tests rebuild to compare against tests/golden/clip_tower.pt."""
+    g = torch.Generator().manual_seed(seed)
+    vit = VisionTransformer(**vision_cfg)
+    sd = {}
+    for k, v in vit.state_dict().items():
+        r = torch.randn(v.shape, generator=g, dtype=torch.float32)
+        if k.endswith(".weight") and v.dim() == 1:          # LayerNorm scale
+            sd[k] = 1.0 + 0.1 * r
+        elif v.dim() == 1 and "class_embedding" not in k:   # biases
+            sd[k] = 0.02 * r
+        elif k in ("class_embedding", "positional_embedding"):
+            sd[k] = 0.05 * r
+        else:                                               # matrices / the patch convolution / proj: fan-in scaled
+            fan_in = v[0].numel() if k != "proj" else v.shape[0]
+            sd[k] = r / fan_in ** 0.5
+    return sd
+
+
+def seeded_image(seed, size):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand((1, 3, *size), generator=g) * 2 - 1
 
 
 @torch.no_grad()

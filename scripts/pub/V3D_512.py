@@ -251,9 +251,10 @@ def main():
                            ignore_alpha=a.ignore_alpha)
     print("frames", frames.shape, frames.dtype, "mean", float(frames.mean()))
     # parity status of what just ran: sampler / U-Net / decoder / VAE encoder are pinned to fixtures generated from the
-    # reference's own modules; the OpenCLIP + kornia image front-end is third-party code absent from the reference tree and this image
-    print("parity: sampler/unet/decoder/vae_encoder pinned to reference fixtures; clip_parity: unpinned (open_clip / kornia not available: "
-          "restated from their published algorithms, oracle/clip_oracle.py)")
+    # reference's own modules; the OpenCLIP ViT tower is pinned to transformers' implementation of the same architecture (tests/golden/clip_tower.pt);
+    # kornia (the antialiased resize in front of it) is third-party code absent from the reference tree and this image
+    print("parity: sampler/unet/decoder/vae_encoder pinned to reference fixtures; clip tower pinned to transformers' CLIPVisionModelWithProjection; "
+          "kornia resize: restated from its published algorithm, unpinned (oracle/clip_oracle.py)")
 
 
 if __name__ == "__main__":

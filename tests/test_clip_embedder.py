@@ -1,5 +1,8 @@
 """CLIP image embedder: plugin classes, state-dict contract, engine vs oracle.
-The oracle for this piece is UNPINNED (open_clip / kornia are absent - see oracle/clip_oracle.py)."""
+The ViT tower of the oracle is PINNED to transformers' CLIPVisionModelWithProjection (tests/golden/clip_tower.pt, oracle/gen_golden_clip.py);
+the kornia resize in front of it is a restatement (kornia is absent - see oracle/clip_oracle.py)."""
+import os
+
 import pytest
 import torch
 
@@ -33,6 +36,51 @@ def build(vision_cfg=None, seed=0):
 def visual_sd(emb):
     pre = "open_clip.model.visual."
     return {k[len(pre):]: v for k, v in emb.state_dict().items() if k.startswith(pre)}
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_tower.pt")
+
+
+@pytest.mark.parametrize("case", ["reduced", "vit_h_14"])
+def test_oracle_tower_is_pinned_to_independent_implementation(case):
+    """clip_oracle.VisionTransformer on the seeded weights / image of the fixture == image_embeds of transformers' CLIP vision tower."""
+    fx = torch.load(GOLDEN)[case]
+    sd = clip_oracle.seeded_visual_state_dict(fx["vision_cfg"], fx["weight_seed"])
+    img = clip_oracle.seeded_image(fx["image_seed"], fx["image_size"])
+    px = clip_oracle.preprocess(img, fx["vision_cfg"]["image_size"], antialias=True)
+    assert abs(float(px.double().sum()) - fx["pixel_checksum"]) <= 1e-3 * max(1.0, abs(fx["pixel_checksum"]))     # same tower input as the generator's
+    got = clip_oracle.image_embedding(sd, fx["vision_cfg"], img)[:, 0]
+    torch.testing.assert_close(got, fx["image_embeds"], rtol=1e-4, atol=1e-4)
+
+
+def load_seeded(emb, fx):
+    sd = clip_oracle.seeded_visual_state_dict(fx["vision_cfg"], fx["weight_seed"])
+    emb.load_state_dict({"open_clip.model.visual." + k: v for k, v in sd.items()})
+    return emb
+
+
+def test_engine_matches_independent_implementation_emulated():
+    """the engine's tower (kernel contracts executed in fp32 on the CPU) against the transformers fixture, reduced depth"""
+    fx = torch.load(GOLDEN)["reduced"]
+    emb = load_seeded(build(fx["vision_cfg"]), fx)
+    img = clip_oracle.seeded_image(fx["image_seed"], fx["image_size"])
+    with use_backend(EmulOps("cpu", exact=True)):
+        got = emb(img)[:, 0]
+    torch.testing.assert_close(got, fx["image_embeds"], rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,tol", [("reduced", 3e-2), ("vit_h_14", 4e-2)])
+def test_hip_tower_matches_independent_implementation(case, tol):
+    """HIP kernels (bf16) against image_embeds of transformers' CLIPVisionModelWithProjection: reduced depth and the full ViT-H/14 on 512 x 512."""
+    from v3d_amd.hip import HipOps
+    fx = torch.load(GOLDEN)[case]
+    emb = load_seeded(build(fx["vision_cfg"]), fx).to("cuda")
+    img = clip_oracle.seeded_image(fx["image_seed"], fx["image_size"])
+    with use_backend(HipOps()):
+        got = emb(img.cuda())[:, 0].float().cpu()
+    rel, cos = rel_cos(got, fx["image_embeds"])
+    assert rel <= tol and cos >= 0.999, (case, rel, cos)
 
 
 def test_state_dict_contract_of_vit_h_14():
