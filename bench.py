@@ -600,6 +600,12 @@ def main():
 
     result = None
     samples = args.steps * (1 if shard_mode else world)
+    ranks_seen = 1
+    if world > 1:
+        # how many ranks actually took part (an all-reduce of ones over RCCL): a SCALE record then shows N ranks were seen, not just requested
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     if rank == 0:
         frames = samples * B_IN * T_FR
         par = f"frame-shard {shard.describe()}" if shard_mode else f"replica x{world}"
@@ -621,6 +627,14 @@ def main():
             "dtype": "bf16 (fp8 e4m3 spatial attention)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": wl, "frames": T_FR, "inputs_per_step": B_IN, "edm_steps": E_STEPS, "latent": [B_IN * T_FR, 4, LH, LW], "parallelism": par},
         }
+        if world > 1:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:      # noqa: BLE001
+                ver = "unknown"
+            result["collectives"] = {"backend": f"torch.distributed nccl = RCCL {ver}", "ranks_requested": world, "ranks_seen": ranks_seen,
+                                     "data_path": ("grouped point-to-point (K|V all-gather, halo + fp64 statistics) between the frame-shard ranks" if shard_mode
+                                                   else "none (independent samples per rank); barrier + max-over-ranks timing only")}
         if headline:
             sample_tflop = STEPS * F_UNET_TFLOP + T_FRAMES * F_VAE_TFLOP_PER_FRAME
             result["achieved_tflops_reference_graph"] = round(samples * sample_tflop / dt, 1)

@@ -10,7 +10,8 @@
  *   (iii) 3-D GroupNorm statistics (openaimodel.py:267-271,302-305)    every rank's fp64 (sum, sumsq) to every rank    } (one grouped call)
  * STATUS: verified on hardware with ONE rank only (communicator creation, grouped self send / recv, the copy / reduction kernels) - the
  * build boxes have one GPU and RCCL refuses two ranks per device; the multi-rank message schedule is the one dist.py runs under gloo with
- * 2 / 4 / 8 ranks in tests/test_dist_gloo.py.  No RCCL timing exists for this path.
+ * 2 / 4 / 8 ranks in tests/test_dist_gloo.py; tests/test_comm_schedule.py holds this library's own send / recv lists (v3d_comm_debug_schedule) to
+ * dist.py's for world 2 / 4 / 8 and checks that every pair of ranks agrees on sizes and order.  No RCCL timing exists for this path.
  * All pointers are device pointers on the current device; return 0 or a negative code, message through v3d_comm_last_error(). */
 #ifndef V3D_COMM_H
 #define V3D_COMM_H
@@ -48,6 +49,12 @@ int v3d_comm_exchange_halo_and_sums(v3d_comm_t comm, void* buf, int64_t B, int32
                                     double* allsums, double* total, int64_t nsums, v3d_comm_stream_t stream);
 /* one grouped ncclSend + ncclRecv of `bytes` bytes from this rank to itself: exercises the grouped point-to-point path on a single GPU */
 int v3d_comm_selftest(v3d_comm_t comm, const void* src, void* dst, int64_t bytes, v3d_comm_stream_t stream);
+
+/* tests / diagnostics (no GPU, no communicator): the (send, peer, buffer, byte offset, bytes) list rank `rank` of `world` would issue inside its ONE group -
+ * kind 0: v3d_comm_allgather_frames (buffer 0 = local, 1 = out); kind 1: v3d_comm_exchange_halo_and_sums (have_buf: halos; nsums > 0: statistics;
+ * buffer 0 = buf, 1 = sums, 2 = allsums).  out holds 5 int64 per message; returns the message count or -1.  The exchanges issue exactly this list. */
+int v3d_comm_debug_schedule(int32_t kind, int32_t rank, int32_t world, int32_t have_buf, int64_t B, int32_t T_global, int64_t frame_bytes, int64_t nsums,
+                            int64_t* out, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -12,10 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _lib():
+    """the library, or a skip where it cannot exist (no hipcc / no RCCL under the ROCm tree / librccl unresolvable): it is optional (v3d_amd/build.py)"""
     from v3d_amd import comm
     from v3d_amd.build import build_comm
-    build_comm(verbose=False)
-    return comm.load_library()
+    try:
+        build_comm(verbose=False)
+        return comm.load_library()
+    except (RuntimeError, OSError) as e:
+        pytest.skip(f"libv3d_comm.so unavailable: {str(e).splitlines()[0]}")
 
 
 def test_header_symbols_are_exported_and_bound():

@@ -94,7 +94,12 @@ def _build(force, verbose, LIBDIR, libname, extra) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if not extra:
-        build_comm(force=force, verbose=verbose)
+        # libv3d_comm.so is OPTIONAL: the Python product path never loads it (dist.py runs the same schedule on torch.distributed), and a box
+        # without rccl.h / librccl under the ROCm tree must still get the kernel library
+        try:
+            build_comm(force=force, verbose=verbose)
+        except Exception as e:      # noqa: BLE001
+            print(f"[v3d_amd.build] WARNING: libv3d_comm.so not built ({str(e).splitlines()[0]}); the kernel library is unaffected", file=sys.stderr)
     return LIB
 
 
@@ -107,8 +112,10 @@ def build_comm(force: bool = False, verbose: bool = True) -> str:
     library (links librccl; the kernel library does not)."""
     hdr = os.path.join(os.path.dirname(HERE), "include", "v3d_comm.h")
     if force or _stale(COMM_LIB, [COMM_SRC, hdr]):
-        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
-        cmd = [_hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", COMM_SRC, "-o", COMM_LIB, f"-L{rocm_lib}", "-lrccl"]
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
+        # rpath: a host that has not loaded torch (whose bundled librccl would otherwise satisfy the dependency) resolves librccl from the ROCm tree
+        cmd = [_hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", COMM_SRC, "-o", COMM_LIB, f"-L{rocm_lib}", "-lrccl",
+               f"-Wl,-rpath,{rocm_lib}"]
         if verbose:
             print("[v3d_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -26,6 +26,7 @@ SIGNATURES = {
     "v3d_comm_allgather_frames": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp]),
     "v3d_comm_exchange_halo_and_sums": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "v3d_comm_selftest": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "v3d_comm_debug_schedule": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i64, c_i64, C.POINTER(c_i64), c_i32]),
 }
 
 
@@ -38,6 +39,16 @@ def load_library(path: Optional[str] = None):
     if v != ABI_VERSION:
         raise RuntimeError(f"libv3d_comm.so ABI version {v} != expected {ABI_VERSION}; rebuild")
     return lib
+
+
+def debug_schedule(lib, kind: int, rank: int, world: int, *, have_buf: bool = True, B: int = 1, T_global: int = 18, frame_bytes: int = 0, nsums: int = 0):
+    """The message list the library would issue (no GPU needed): [(send, peer, buffer, offset, bytes), ...] - see include/v3d_comm.h."""
+    cap = 4096
+    out = (c_i64 * (5 * cap))()
+    n = lib.v3d_comm_debug_schedule(kind, rank, world, int(have_buf), B, T_global, frame_bytes, nsums, out, cap)
+    if n < 0:
+        raise ValueError(lib.v3d_comm_last_error().decode())
+    return [tuple(int(out[5 * i + j]) for j in range(5)) for i in range(n)]
 
 
 def frame_range(lib, T_global: int, world: int, rank: int):
