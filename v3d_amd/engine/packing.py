@@ -371,6 +371,10 @@ def cross_attn_pack(p: SVTPack, which: str):
     """(norm2, W_q [C, C], W_k | W_v [2C, ctx_dim], W_o [C, C], b_o) of the spatial ("s") / temporal ("t") attn2 of a transformer block, for contexts of
     more than one token (CrossAttention.forward, attention.py:286-349: to_q / to_k / to_v without bias, to_out[0] with bias).  Packed on first use."""
     if which not in p.x2:
+        # first use must not happen inside a HIP-graph capture: the packed weights would be allocated in the graph's private pool (and their
+        # conversion kernels recorded into the graph) and then cached for later eager calls (ADVICE r5) - run one eager evaluation first
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("cross_attn_pack: first multi-token cross-attention evaluation inside a HIP-graph capture; run one eager evaluation before capturing")
         attn, norm = (p.s_attn2, p.s_norm2) if which == "s" else (p.t_attn2, p.t_norm2)
         wq = _bf(attn.to_q.weight)
         wkv = _bf(torch.cat([attn.to_k.weight.detach(), attn.to_v.weight.detach()], dim=0))
