@@ -277,7 +277,7 @@ def measure_rooflines(step):
                  "kernels_changed_since": pmc.get("csrc_sha256_16") != csrc_digest()}
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "v3d_gemm family: conv_halo_kernel (GroupNorm + SiLU + conv3x3 / conv(3,1,1) in one kernel) + gemm_kernel_v3 / v2 (conv3x3 / convt3 / linear / GEGLU launches, incl. the GroupNorm-statistics epilogue of the 3x3 convolutions) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards) + ln_proj_kernel<320> (LayerNorm + q|k|v projection)",
+    return {"bound": "mfma", "kernel": "v3d_gemm family: conv_halo_kernel (GroupNorm + SiLU + conv3x3 / conv(3,1,1) in one kernel) + gemm_kernel_v3 / v6 / v2 (conv3x3 / convt3 / linear / GEGLU launches, incl. the GroupNorm-statistics epilogue of the 3x3 convolutions) + ff_fused_kernel<320> (both GEMMs of the 64x64 feed-forwards) + ln_proj_kernel<320> (LayerNorm + q|k|v projection)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, U-Net launches (rocprofv3 PMC passes)", "traffic_profile": tinfo,
             "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)), "launches_per_sample": n, "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2),

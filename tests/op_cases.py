@@ -70,7 +70,7 @@ def case_groupnorm_small(hip, emu, dev, *, n_img, S, C1, C2=0, imgs_per_stat=1, 
 
 
 def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=True, add=False, res=0, coef=False,
-              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0, gn_rps=0, expect_streamk=None):
+              out_fp32=False, conv=None, convt=None, batch=1, lda_pad=0, seed=0, shared_w=True, pad_mode=0, gn_rps=0, expect_streamk=None, expect_family=None):
     """gn_rps > 0: the launch also gathers the GroupNorm partial sums of its output (GemmCall.gn_stats, 32 groups, gn_rps rows per statistics
     group); they are checked against sums over the rows the kernel itself stored (fp32 partials, one slot per writer: 2e-4 of the largest sum)
     and a second launch must reproduce output AND statistics bit for bit (no atomics anywhere)."""
@@ -139,6 +139,13 @@ def case_gemm(hip, emu, dev, *, M, N, K, mode=GEMM_LINEAR, geglu=False, bias=Tru
         return compare(out_h, out_e)
     sk0 = _sk_counter(hip, "v3d_debug_sk_launches") if expect_streamk is not None else 0
     hip.gemm(GemmCall(out=out_h, **base))
+    if expect_family is not None and getattr(hip, "name", "") == "hip" and not any(os.environ.get(k) for k in ("V3D_GEMM_IMPL", "V3D_GEMM_CFG", "V3D_GEMM_V6")):
+        # the dispatcher's choice under the default policy (gemm.hip dispatch): 6 = two persistent 4-wave blocks per CU on 192 x 160 tiles
+        fam = hip.last_gemm_launch()["family"]
+        assert fam == expect_family, f"expected kernel family {expect_family}, the library launched {hip.last_gemm_launch()}"
+        out_2 = torch.zeros_like(out_h)
+        hip.gemm(GemmCall(out=out_2, **base))
+        assert torch.equal(out_2, out_h), "two identical launches differ"
     if expect_streamk is not None:
         # stream-K tail of the persistent v3 kernels (the last round's tiles shared out over all CUs): taken / not taken as the plan says,
         # and a second launch reproduces the first bit for bit (partials are added in block order)
@@ -661,6 +668,11 @@ def all_cases(full: bool = True):
             ("lin_V3D_L1_ffout_partial_round", case_gemm, dict(M=36864, N=640, K=2560, res=2, expect_streamk=False, seed=32), TOL_BF16),
             ("convt3_V3D_L2_partial_round", case_gemm, dict(M=0, N=1280, K=1280, mode=CT, convt=(2, 18, 256, 0, 0, 17), res=1, add=True, expect_streamk=False, seed=34), TOL_BF16),
             ("convt3_V3D_L1", case_gemm, dict(M=0, N=640, K=640, mode=CT, convt=(2, 18, 1024, 0, 0, 17), res=1, coef=True, add=True), TOL_BF16),
+            # round 6: the 192 x 160 tiles on two 4-wave blocks per CU (gemm_kernel_v6) where v3's tiles leave a partial round
+            ("lin_V3D_L1_640_v6", case_gemm, dict(M=36864, N=640, K=640, add=True, res=1, expect_family=6, seed=41), TOL_BF16),
+            ("lin_V3D_L1_640_v6_res2", case_gemm, dict(M=36864, N=640, K=640, res=2, expect_family=6, seed=42), TOL_BF16),
+            ("lin_V3D_L2_qkv_v6", case_gemm, dict(M=9216, N=3840, K=1280, bias=False, expect_family=6, seed=43), TOL_BF16),
+            ("lin_V3D_L0_320_stays_v3", case_gemm, dict(M=147456, N=320, K=320, add=True, res=1, expect_family=3, seed=44), TOL_BF16),
             ("gn2d_V3D_960_64x64", case_groupnorm, dict(n_img=4, S=4096, C1=640, C2=320), TOL_BF16),
             ("gn3d_V3D_L2", case_groupnorm, dict(n_img=36, S=256, C1=1280, imgs_per_stat=18), TOL_BF16),
             ("ln_V3D_L0", case_layernorm, dict(M=2 * 4096, C=320, add=True), TOL_BF16),

@@ -11,9 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl,extra", [("1", {}), ("2", {}), ("3", {}), ("2", {"V3D_GEMM_SPLITK": "3"}), ("3", {"V3D_GEMM_V3S": "0"})])
+@pytest.mark.parametrize("impl,extra", [("1", {}), ("2", {}), ("3", {}), ("2", {"V3D_GEMM_SPLITK": "3"}), ("3", {"V3D_GEMM_V3S": "0"}), ("", {"V3D_GEMM_V6": "2"})])
 def test_gemm_parity_with_forced_impl(impl, extra):
-    env = dict(os.environ, V3D_GEMM_IMPL=impl, **extra)
+    """("", V3D_GEMM_V6=2): every linear launch the two-blocks-per-CU kernel can take (M % 192 == 0, N % 160 == 0, >= 2 tiles per CU) goes to it"""
+    env = dict(os.environ, **({"V3D_GEMM_IMPL": impl} if impl else {}), **extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_sweep.py"), "--check", "--only=__none__"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -20,7 +20,7 @@ def wrap(name, keyfn):
         key = keyfn(*a, **k)
         if name == "gemm":       # + the library's own record of the kernel that took the launch (family, tile, tiles, fill)
             li = ops.last_gemm_launch()
-            fam = {1: "v1", 2: "v2", 3: "v3", 5: "halo"}.get(li["family"], "?") + (f"/sk{li['splitk']}" if li["splitk"] > 1 else "") + ("/tail" if li["streamk_tail"] else "")
+            fam = {1: "v1", 2: "v2", 3: "v3", 5: "halo", 6: "v6"}.get(li["family"], "?") + (f"/sk{li['splitk']}" if li["splitk"] > 1 else "") + ("/tail" if li["streamk_tail"] else "")
             key = (key[0] + f"  <{fam} {li['bm']}x{li['bn']} tiles={li['tiles']} x{li['blocks_per_cu']}/CU fill={li['fill']:.2f}>", key[1])
         rec.append((key, e0, e1))
         return r

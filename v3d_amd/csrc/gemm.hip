@@ -31,6 +31,12 @@
 //   V3D_GEMM_TAPINNER 1 = (k outer, tap inner) stage order.  It removes the 7-19x L2-miss re-reads of the K >= 640 convolutions but recomputes
 //                     the per-lane row offsets every 32-k step: 25-30 % SLOWER on every convolution (1044 -> 769 TF/s at 1920 -> 640) - the
 //                     loaders have no VALU to spare, the re-reads come from the Infinity Cache and are not what bounds these launches.  Off.
+#ifndef V3D_GEMM_V6_DEFAULT
+#define V3D_GEMM_V6_DEFAULT 1
+#endif
+#ifndef V3D_GEMM_V6_MIN_TILES
+#define V3D_GEMM_V6_MIN_TILES 512
+#endif
 #ifndef V3D_GEMM_TAPINNER_DEFAULT
 #define V3D_GEMM_TAPINNER_DEFAULT 0
 #endif
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
                 E4GnRun<WM, MF> run;
                 if constexpr (GN) run.init(mw0, p.gn_rps);
                 auto flushfn = [&](int f, long long, unsigned& slot, unsigned& sid) __attribute__((always_inline)) -> bool { return run.step(f, slot, sid); };
-                e4_retire_tile<MF, NF, GN>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
+                e4_retire_tile<MF, NF, GN, (MODE == V3D_GEMM_LINEAR ? E4_DEPTH_LINEAR : E4_DEPTH)>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
             }
         } else
         {
@@ -568,6 +574,148 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (DBG && dbg_on && lane < 32)
         for (int k = 0; k < 8; ++k) g_v3_dbg[(grp * 32 + lane) * 8 + k] = dbg[(grp * 32 + lane) * 8 + k];
+}
+
+// =====================================================================================================================
+// v6: persistent 4-wave blocks, TWO per CU, for the HBM-bound linears (K <= 640: to_out / proj_in / proj_out / skip of the 64 x 64 and 32 x 32 levels)
+// =====================================================================================================================
+// Why (round 6, tools/v3_timeline_k320.py -> profiles/r06_timeline_k320_*.txt): on M = 147456, N = K = 320 the v3 block spends 25 k cycles in the ten
+// steps of a tile (8 k of them waiting for rows from HBM) and then 14 k (bias only) to 33 k (bias + vector + residual) cycles in the tile's epilogue,
+// with NO load of the next tile issued meanwhile beyond the three ring stages - every CU of the chip alternates between a read phase and a
+// (read +) write phase, each bound by the bytes one block keeps in flight, and the launch moves 3.4 TB/s.  The work of a CU has to be two
+// independent streams whose phases overlap.  The wave groups of a v3 block cannot be that (one s_barrier per workgroup), so here the groups
+// are BLOCKS: 256 threads, 192 x 160 tiles (wave tile 96 x 80 as v3's 192 x 320: same fragments, same hand-managed epilogue), a 3-stage
+// ring of 22-KiB stages -> 79 KiB of LDS and 256 registers per wave: two blocks per CU, each with its own ring, barrier and tile sequence.
+// While one block retires a tile the other runs its main loop: its LDS-DMA stream and the first block's residual loads / row stores share
+// the memory system instead of taking turns.  The two N-halves of a row tile are consecutive tile ids (row-major walk) = blocks 8 apart on one
+// XCD: the second reader of the 192 activation rows finds them in that XCD's L2.
+// One wave per SIMD and block, so a wave runs {fragment reads, DMA issue, MFMAs, counted wait, barrier} in sequence and the co-resident block's
+// wave fills the matrix pipe meanwhile - unsynchronised, which is fine for launches that are bound by HBM, not by the matrix pipe.
+template <int BM, int BN, int NS, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v6(GP p, int ntiles) {
+    constexpr int ROWB = 64, NW = 4, WGN = 2;
+    constexpr int WM = BM / 2, WN = BN / WGN, MF = WM / 16, NF = WN / 16;
+    static_assert(NF == 5 || NF == 4, "the hand-managed epilogue retires 80- or 64-channel wave tiles");
+    constexpr int NPIECE = (BM + BN) / 16, PPW = (NPIECE + NW - 1) / NW, APIECES = BM / 16;
+    static_assert(APIECES % NW == 0 && PPW * (NS - 2) < 64, "activation pieces per wave / vmcnt range");
+    constexpr int STAGE_BYTES = NPIECE * 1024;
+    constexpr int DUMMY_OFF = NS * STAGE_BYTES, NDUMMY = PPW * NW - NPIECE;        // pieces past the stage keep every wave's DMA count per stage equal
+    constexpr int EPI_OFF = DUMMY_OFF + NDUMMY * 1024, EPI_REGION = 16 * (NF * 32 + 16);
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[EPI_OFF + NW * EPI_REGION];      // the ONLY __shared__ object
+    static_assert(sizeof(lds) <= 80 * 1024, "two blocks per CU");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    unsigned char* estage = lds + EPI_OFF + wave * EPI_REGION;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    auto tile_origin = [&](int it, long long& m0, long long& n0) __attribute__((always_inline)) {
+        const int id = xcd_remap((int)blockIdx.x + it * G, ntiles);
+        int tm, tn;
+        tile_coords(p, id, tm, tn);
+        n0 = (long long)tn * BN;
+        m0 = (long long)tm * BM;
+    };
+    // ---- loader (as v3): piece q = wave + 4 i; i < APIECES / 4: activation rows, then weight rows, then (q >= NPIECE) a dummy into its own KiB
+    const bufrsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const bufrsrc_t rsW = make_rsrc(p.W, p.w_bytes);
+    const int prow = lane >> 2;
+    const unsigned kchunk_b = (unsigned)(((lane & 3) ^ swz_row<1>(prow)) * 16);
+    RowInfo<MODE> ri[APIECES / NW];
+    unsigned voff[PPW];
+    long long ld_n0 = 0;
+    int ld_it = 0, ld_k0 = 0;
+    auto set_tile = [&](int it) __attribute__((always_inline)) {
+        long long m0;
+        tile_origin(it, m0, ld_n0);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave + NW * i;
+            if (i < APIECES / NW) {
+                ri[i].init(p, m0 + q * 16 + prow);
+                long long s_;
+                const bool ok = ri[i].tap(p, 0, s_);
+                voff[i] = ok ? (unsigned)((s_ + p.a_row0) * p.lda * 2) + kchunk_b : kInvalid;
+            } else {
+                const long long n = ld_n0 + (q - APIECES) * 16 + prow;
+                voff[i] = (q < NPIECE && n < p.N) ? (unsigned)(n * p.ldw * 2) + kchunk_b : kInvalid;
+            }
+        }
+    };
+    set_tile(0);
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const int so = __builtin_amdgcn_readfirstlane(ld_k0 * 2);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave + NW * i;
+            const int dst = q < NPIECE ? stage * STAGE_BYTES + q * 1024 : DUMMY_OFF + (q - NPIECE) * 1024;
+            if V3D_ABL(p, 4) continue;
+            const unsigned vo = (V3D_ABL(p, 2048) && i < APIECES / NW) ? kInvalid : voff[i];      // (experiments: no fetch of the activation rows)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < APIECES / NW ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + dst), 16, (int)vo, so, 0, 0);
+        }
+        ld_k0 += 32;
+        if (ld_k0 >= (int)p.K) {
+            ld_k0 = 0;
+            if (++ld_it < my_tiles) set_tile(ld_it);      // past the last tile: harmless re-reads keep the DMA count constant
+        }
+    };
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag_off = (lane & 15) * ROWB + (((lane >> 4) ^ swz_row<1>(lane & 15)) * 16);
+    const int a_base = wm * WM * ROWB;
+    const int b_base = BM * ROWB + wn * WN * ROWB;
+    bf16x8 xf[MF], wf[NF];
+    const int nsteps = (int)(p.K / 32);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue(st);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();   // stage 0 landed
+    __builtin_amdgcn_sched_barrier(0);
+    int rd = 0;       // ring slot of the current step; the refill target (step s + NS - 1) is the slot before it, whose readers passed the last barrier
+    for (int it = 0; it < my_tiles; ++it) {
+        for (int kt = 0; kt < nsteps; ++kt) {
+            {
+                const unsigned char* sb = lds + rd * STAGE_BYTES;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + frag_off + i * 16 * ROWB);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_base + frag_off + j * 16 * ROWB);
+            }
+            issue(rd == 0 ? NS - 1 : rd - 1);
+            rd = (rd + 1 == NS) ? 0 : rd + 1;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (!V3D_ABL(p, 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");   // own pieces of the next stage landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        long long e_m0, e_n0;
+        tile_origin(it, e_m0, e_n0);
+        const long long mw0 = e_m0 + wm * WM, nw0 = e_n0 + wn * WN;
+        if (mw0 < p.M && nw0 < p.N) {
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));          // (keeps what the epilogue derives from the lane id out of the loop-invariant set: no spills)
+            auto rowfn = [&](int f) __attribute__((always_inline)) -> long long { return mw0 + f * 16; };
+            auto flushfn = [&](int, long long, unsigned&, unsigned&) __attribute__((always_inline)) -> bool { return false; };
+            e4_retire_tile<MF, NF, false, E4_DEPTH_V6>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---- split-K finalize: out = epilogue(sum over splits of ws) element-wise (4 consecutive channels per thread) ---------------------
@@ -842,7 +990,8 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
     const int grid = ntiles < v3d_num_cus() ? ntiles : v3d_num_cus();
     if constexpr (MODE == V3D_GEMM_LINEAR && !GEGLU) {
         if V3D_ABL(p, 8) {
-            V3D_LAUNCH(3, 256, 256, ntiles, (gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, true>), dim3(grid), 512, st, p, ntiles);
+            if (variant == 1) V3D_LAUNCH(3, 192, 320, ntiles, (gemm_kernel_v3<192, 320, 2, 4, MODE, GEGLU, 1, true>), dim3(grid), 512, st, p, ntiles);
+            else V3D_LAUNCH(3, 256, 256, ntiles, (gemm_kernel_v3<256, 256, 2, 4, MODE, GEGLU, 1, true>), dim3(grid), 512, st, p, ntiles);
             return v3d_check_launch("v3d_gemm");
         }
     }
@@ -888,8 +1037,43 @@ int launch_v3(const GP& p0, hipStream_t st, int variant) {
     return v3d_check_launch("v3d_gemm");
 }
 
+// v6 (two persistent 4-wave blocks per CU).  V3D_GEMM_V6: 0 = never, 1 = where v3's tiles quantise badly (the rule in dispatch), 2 = every legal launch (A/B knob)
+int v6_choice() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("V3D_GEMM_V6");
+        v = e ? atoi(e) : V3D_GEMM_V6_DEFAULT;
+    }
+    return v;
+}
+int launch_v6(const GP& p0, hipStream_t st) {
+    GP p = p0;
+    p.mt = (int)(p.M / 192);
+    p.nt = (int)(p.N / 160);
+    p.group_m = 0;                       // row-major walk: the N-tiles of a row tile are consecutive ids -> blocks 8 apart on one XCD share its activation rows in L2
+    const int ntiles = p.mt * p.nt;
+    const int grid = ntiles < 2 * v3d_num_cus() ? ntiles : 2 * v3d_num_cus();
+    V3D_LAUNCH(6, 192, 160, ntiles, (gemm_kernel_v6<192, 160, 3, V3D_GEMM_LINEAR>), dim3(grid), 256, st, p, ntiles);
+    return v3d_check_launch("v3d_gemm(v6)");
+}
+
 template <int MODE, bool GEGLU>
 int dispatch(const GP& p, int batch, hipStream_t st) {
+    if constexpr (MODE == V3D_GEMM_LINEAR && !GEGLU) {
+        // v6 (192 x 160 tiles on two 4-wave blocks per CU) where the 192 x 320 / 256 x 256 tiles of v3 quantise badly on the CUs: measured
+        // (profiles/r06_v6_ab.txt) -9 ... -14 % on the M = 9216 projections and the N = K = 640 linears (1.4 - 2.25 rounds of v3 tiles), a tie where
+        // v3's tiles fill >= 0.9 of their rounds, +1 ... 6 % where v3 runs full rounds (N = 320 at 64 x 64, M = 36864 N = 1280) - those stay on v3.
+        const int v6 = v6_choice();
+        if (v6 && impl_choice() == 0 && cfg_choice() < 0 && batch == 1 && p.K % 32 == 0 && p.K * 2 <= 65536 && p.N % 160 == 0 && p.M % 192 == 0 && !p.gn_stats && e4_ok(p, 96, 80)) {
+            const long long cus = v3d_num_cus(), t6 = (p.M / 192) * (p.N / 160);
+            const bool v1 = p.N % 320 == 0;
+            const long long bm = v1 ? 192 : 256, bn = v1 ? 320 : 256;
+            const long long t3 = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+            const double fill3 = (double)t3 / (double)(((t3 + cus - 1) / cus) * cus) * ((double)p.N / (double)(((p.N + bn - 1) / bn) * bn));
+            const double fill6 = (double)t6 / (double)(((t6 + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+            if (t6 >= V3D_GEMM_V6_MIN_TILES * cus / 256 && (v6 >= 2 || (p.K <= 1280 && fill3 < 0.9 && fill6 >= fill3))) return launch_v6(p, st);      // (K = 2560: a tie with v2)
+        }
+    }
     // v3 (persistent big tiles) unless forced off (V3D_GEMM_IMPL=1/2), forced on (=3), or the tile count fills the CUs badly
     if (impl_choice() != 1 && impl_choice() != 2 && cfg_choice() < 0 && batch == 1 && p.K % 32 == 0 && p.K * 2 <= 65536 && p.N >= 256) {
         const int variant = (!GEGLU && p.N % 320 == 0) ? 1 : 0;

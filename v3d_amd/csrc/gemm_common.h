@@ -721,7 +721,7 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
     for (int k = 0; k < (NP + 63) / 64; ++k) {
         const int c = k * 64 + lane;
         const int row = c / CPRO, ch = c % CPRO;
-        if (NP % 64 == 0 || c < NP) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
+        if ((NP % 64 == 0 || c < NP) && !V3D_ABL(p, 1)) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
     }
 }
 
@@ -730,6 +730,13 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
 // main loop's operand fragments are dead here) the wave pays the latency once per tile, in the constants' wait, not once per fragment.
 #ifndef E4_DEPTH
 #define E4_DEPTH 1
+#endif
+// the LINEAR v3 kernels have the registers for a deeper look-ahead (248-254 VGPRs, no spills at depth 2 / 3; the multi-tap loaders spill: depth 1)
+#ifndef E4_DEPTH_LINEAR
+#define E4_DEPTH_LINEAR 1
+#endif
+#ifndef E4_DEPTH_V6
+#define E4_DEPTH_V6 2
 #endif
 template <int NF>
 struct E4Cnt {
@@ -775,11 +782,10 @@ struct E4AccArray {
         for (int j = 0; j < NF; ++j) out[j] = a[F][j];
     }
 };
-template <int F, int MF, int NF, bool GN, typename Acc, typename RowFn, typename FlushFn>
+template <int F, int MF, int NF, bool GN, int D, typename Acc, typename RowFn, typename FlushFn>
 __device__ __forceinline__ void e4_retire(const GP& p, const Acc& acc, long long nw0, int lane, unsigned char* stage, E4Res cur, E4Res n1, E4Res n2,
                                           E4Tile<NF> t, GnAcc<GN ? NF : 1>& gn, RowFn rowfn, FlushFn flushfn) {
     if constexpr (F < MF) {
-        constexpr int D = E4_DEPTH;
         static_assert(D >= 1 && D <= 3, "residual look-ahead: 1..3 fragments");
         const long long m0f = rowfn(F);
         const bool has1 = p.res1 != nullptr;
@@ -815,12 +821,11 @@ __device__ __forceinline__ void e4_retire(const GP& p, const Acc& acc, long long
             unsigned slot = 0, sid = 0;
             if (flushfn(F, m0f, slot, sid)) gn_flush<NF>(p, gn, (long long)sid, nw0, lane, stage, slot);
         }
-        e4_retire<F + 1, MF, NF, GN>(p, acc, nw0, lane, stage, n1, n2, n3, t, gn, rowfn, flushfn);
+        e4_retire<F + 1, MF, NF, GN, D>(p, acc, nw0, lane, stage, n1, n2, n3, t, gn, rowfn, flushfn);
     }
 }
-template <int MF, int NF, bool GN, typename Acc, typename RowFn, typename FlushFn>
+template <int MF, int NF, bool GN, int D = E4_DEPTH, typename Acc, typename RowFn, typename FlushFn>
 __device__ __forceinline__ void e4_retire_tile_src(const GP& p, const Acc& acc, long long nw0, int lane, unsigned char* stage, RowFn rowfn, FlushFn flushfn) {
-    constexpr int D = E4_DEPTH;
     E4Res r0, r1, r2;
     r0.a0 = r0.a1 = r0.a2 = u32x4{0u, 0u, 0u, 0u};
     r1 = r0;
@@ -835,11 +840,11 @@ __device__ __forceinline__ void e4_retire_tile_src(const GP& p, const Acc& acc, 
     asm volatile("" : "+v"(r0.a0), "+v"(r0.a1), "+v"(r0.a2), "+v"(r1.a0), "+v"(r1.a1), "+v"(r1.a2), "+v"(r2.a0), "+v"(r2.a1), "+v"(r2.a2));
     GnAcc<GN ? NF : 1> gn;
     if constexpr (GN) gn_zero(gn);
-    e4_retire<0, MF, NF, GN>(p, acc, nw0, lane, stage, r0, r1, r2, t, gn, rowfn, flushfn);
+    e4_retire<0, MF, NF, GN, D>(p, acc, nw0, lane, stage, r0, r1, r2, t, gn, rowfn, flushfn);
 }
-template <int MF, int NF, bool GN, typename RowFn, typename FlushFn>
+template <int MF, int NF, bool GN, int D = E4_DEPTH, typename RowFn, typename FlushFn>
 __device__ __forceinline__ void e4_retire_tile(const GP& p, f32x4 (&acc)[MF][NF], long long nw0, int lane, unsigned char* stage, RowFn rowfn, FlushFn flushfn) {
-    e4_retire_tile_src<MF, NF, GN>(p, E4AccArray<MF, NF>{acc}, nw0, lane, stage, rowfn, flushfn);
+    e4_retire_tile_src<MF, NF, GN, D>(p, E4AccArray<MF, NF>{acc}, nw0, lane, stage, rowfn, flushfn);
 }
 
 // ---- stream-K tail ------------------------------------------------------------------------------------------------------------------------

@@ -143,7 +143,7 @@ class HipOps(OpsBase):
 
     def last_gemm_launch(self) -> dict:
         """What the last `gemm` of this thread actually launched (the library's own record, gemm.hip v3d_debug_last_gemm_launch): kernel family
-        (1 = v1, 2 = v2, 3 = persistent v3, 5 = LDS-haloed), tile, tile count, co-resident blocks per CU, split-K ways, stream-K tail - and `fill`,
+        (1 = v1, 2 = v2, 3 = persistent v3, 5 = LDS-haloed, 6 = two persistent 4-wave blocks per CU), tile, tile count, co-resident blocks per CU, split-K ways, stream-K tail - and `fill`,
         the fraction of the CU slots the launch keeps busy over its rounds (1.0 with a stream-K tail: the last round is shared out)."""
         fn = self.lib.v3d_debug_last_gemm_launch
         fn.restype, fn.argtypes = c_i32, [c_vp]
