@@ -92,6 +92,7 @@ def build_cases(hip0, only):
     conv("ct_L0_320_gnin", 320, 320, convt=(2, 18, 4096), res=True, gn_out=False)
     conv("ct_L0_320_plain", 320, 320, convt=(2, 18, 4096), add=True, gn_out=False, gn_in=False)     # v3 CONVT3
     conv("ct_L1_640_plain", 640, 640, convt=(2, 18, 1024), res=True, gn_out=False, gn_in=False)
+    conv("ct_L2_1280_plain", 1280, 1280, convt=(2, 18, 256), res=True, gn_out=False, gn_in=False)
     conv("c3_L1_plain_640", 640, 640, conv=(36, 32, 32), gn_out=False, gn_in=False)                   # v3 CONV3X3 (VAE / strided family)
     # linears (v3 192 x 320 / v2), attention + feed-forward projections
     lin("lin_L0_320_bar", 36 * 4096, 320, 320, add=True, res=True)

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_kernel_v3(GP p, int
         int tm, tn;
         tile_coords(p, id, tm, tn);
         n0 = (long long)tn * BN;
-        m0 = (long long)tm * BM;
+        m0 = p.m_off + (long long)tm * BM;
     };
 
     // ---- loader state (runs up to 3 stages ahead of the consumer, across tile boundaries).  Raw buffer loads straight to
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v6(GP p, int ntiles) {
     constexpr int ROWB = 64, NW = 4, WGN = 2;
     constexpr int WM = BM / 2, WN = BN / WGN, MF = WM / 16, NF = WN / 16;
     static_assert(NF == 5 || NF == 4, "the hand-managed epilogue retires 80- or 64-channel wave tiles");
-    constexpr int NPIECE = (BM + BN) / 16, PPW = (NPIECE + NW - 1) / NW, APIECES = BM / 16;
-    static_assert(APIECES % NW == 0 && PPW * (NS - 2) < 64, "activation pieces per wave / vmcnt range");
+    constexpr int NPIECE = (BM + BN) / 16, PPW = (NPIECE + NW - 1) / NW, APIECES = BM / 16, ARI = (APIECES + NW - 1) / NW;
+    static_assert(PPW * (NS - 2) < 64, "vmcnt range");
     constexpr int STAGE_BYTES = NPIECE * 1024;
     constexpr int DUMMY_OFF = NS * STAGE_BYTES, NDUMMY = PPW * NW - NPIECE;        // pieces past the stage keep every wave's DMA count per stage equal
     constexpr int EPI_OFF = DUMMY_OFF + NDUMMY * 1024, EPI_REGION = 16 * (NF * 32 + 16);
@@ -616,33 +616,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v6(GP p, int ntiles) {
         int tm, tn;
         tile_coords(p, id, tm, tn);
         n0 = (long long)tn * BN;
-        m0 = (long long)tm * BM;
+        m0 = p.m_off + (long long)tm * BM;
     };
-    // ---- loader (as v3): piece q = wave + 4 i; i < APIECES / 4: activation rows, then weight rows, then (q >= NPIECE) a dummy into its own KiB
+    // ---- loader (as v3): piece q = wave + 4 i: q < APIECES activation rows, q < NPIECE weight rows, else a dummy into its own KiB
     const bufrsrc_t rsA = make_rsrc(p.A, p.a_bytes);
     const bufrsrc_t rsW = make_rsrc(p.W, p.w_bytes);
     const int prow = lane >> 2;
     const unsigned kchunk_b = (unsigned)(((lane & 3) ^ swz_row<1>(prow)) * 16);
-    RowInfo<MODE> ri[APIECES / NW];
+    RowInfo<MODE> ri[ARI];
     unsigned voff[PPW];
     long long ld_n0 = 0;
-    int ld_it = 0, ld_k0 = 0;
+    int ld_it = 0, ld_tap = 0, ld_k0 = 0;
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave + NW * i;
+            if (i < ARI && q < APIECES) {
+                long long s_;
+                const bool ok = ri[i < ARI ? i : 0].tap(p, tap, s_);
+                voff[i] = ok ? (unsigned)((s_ + p.a_row0) * p.lda * 2) + kchunk_b : kInvalid;
+            } else {
+                const long long n = ld_n0 + (q - APIECES) * 16 + prow;
+                voff[i] = (q < NPIECE && n < p.N) ? (unsigned)(((long long)tap * p.N + n) * p.ldw * 2) + kchunk_b : kInvalid;
+            }
+        }
+    };
     auto set_tile = [&](int it) __attribute__((always_inline)) {
         long long m0;
         tile_origin(it, m0, ld_n0);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
+        for (int i = 0; i < ARI; ++i) {
             const int q = wave + NW * i;
-            if (i < APIECES / NW) {
-                ri[i].init(p, m0 + q * 16 + prow);
-                long long s_;
-                const bool ok = ri[i].tap(p, 0, s_);
-                voff[i] = ok ? (unsigned)((s_ + p.a_row0) * p.lda * 2) + kchunk_b : kInvalid;
-            } else {
-                const long long n = ld_n0 + (q - APIECES) * 16 + prow;
-                voff[i] = (q < NPIECE && n < p.N) ? (unsigned)(n * p.ldw * 2) + kchunk_b : kInvalid;
-            }
+            if (q < APIECES) ri[i].init(p, m0 + q * 16 + prow);
         }
+        set_tap(0);
     };
     set_tile(0);
     auto issue = [&](int stage) __attribute__((always_inline)) {
@@ -652,13 +659,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v6(GP p, int ntiles) {
             const int q = wave + NW * i;
             const int dst = q < NPIECE ? stage * STAGE_BYTES + q * 1024 : DUMMY_OFF + (q - NPIECE) * 1024;
             if V3D_ABL(p, 4) continue;
-            const unsigned vo = (V3D_ABL(p, 2048) && i < APIECES / NW) ? kInvalid : voff[i];      // (experiments: no fetch of the activation rows)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(i < APIECES / NW ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + dst), 16, (int)vo, so, 0, 0);
+            const unsigned vo = (V3D_ABL(p, 2048) && q < APIECES) ? kInvalid : voff[i];      // (experiments: no fetch of the activation rows)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q < APIECES ? rsA : rsW, (__attribute__((address_space(3))) void*)(lds + dst), 16, (int)vo, so, 0, 0);
         }
         ld_k0 += 32;
         if (ld_k0 >= (int)p.K) {
             ld_k0 = 0;
-            if (++ld_it < my_tiles) set_tile(ld_it);      // past the last tile: harmless re-reads keep the DMA count constant
+            if (++ld_tap < ntaps<MODE>()) {
+                set_tap(ld_tap);
+            } else {
+                ld_tap = 0;
+                if (++ld_it < my_tiles) set_tile(ld_it);      // past the last tile: harmless re-reads keep the DMA count constant
+                else if (ntaps<MODE>() > 1) set_tap(0);
+            }
         }
     };
     f32x4 acc[MF][NF];
@@ -670,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v6(GP p, int ntiles) {
     const int a_base = wm * WM * ROWB;
     const int b_base = BM * ROWB + wn * WN * ROWB;
     bf16x8 xf[MF], wf[NF];
-    const int nsteps = (int)(p.K / 32);
+    const int nsteps = (int)(p.K / 32) * ntaps<MODE>();
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st) issue(st);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (NS - 2)) : "memory");
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_v6(GP p, int ntiles) {
             asm volatile("" : "+v"(lane_e));          // (keeps what the epilogue derives from the lane id out of the loop-invariant set: no spills)
             auto rowfn = [&](int f) __attribute__((always_inline)) -> long long { return mw0 + f * 16; };
             auto flushfn = [&](int, long long, unsigned&, unsigned&) __attribute__((always_inline)) -> bool { return false; };
-            e4_retire_tile<MF, NF, false, E4_DEPTH_V6>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
+            e4_retire_tile<MF, NF, false, (MODE == V3D_GEMM_LINEAR ? E4_DEPTH_V6 : 1)>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -981,10 +994,11 @@ thread_local bool g_gn_in_epilogue = false;
 long long g_gn_epilogue_launches = 0;      // (tests: how many launches of this process gathered the statistics in their epilogue)
 
 template <int MODE, bool GEGLU>
-int launch_v3(const GP& p0, hipStream_t st, int variant) {
+int launch_v3(const GP& p0, hipStream_t st, int variant, long long m_off = 0, long long m_rows = -1) {
     GP p = p0;
     const int bm = variant == 1 ? 192 : 256, bn = variant == 1 ? 320 : (variant == 2 ? 128 : 256);
-    p.mt = (int)((p.M + bm - 1) / bm);
+    p.m_off = m_off;                                        // (split launches: rows [m_off, m_off + m_rows) of the operation)
+    p.mt = (int)(((m_rows > 0 ? m_rows : p.M) + bm - 1) / bm);
     p.nt = (int)((p.N + bn - 1) / bn);
     const int ntiles = p.mt * p.nt;
     const int grid = ntiles < v3d_num_cus() ? ntiles : v3d_num_cus();
@@ -1046,6 +1060,7 @@ int v6_choice() {
     }
     return v;
 }
+template <int MODE>
 int launch_v6(const GP& p0, hipStream_t st) {
     GP p = p0;
     p.mt = (int)(p.M / 192);
@@ -1053,25 +1068,38 @@ int launch_v6(const GP& p0, hipStream_t st) {
     p.group_m = 0;                       // row-major walk: the N-tiles of a row tile are consecutive ids -> blocks 8 apart on one XCD share its activation rows in L2
     const int ntiles = p.mt * p.nt;
     const int grid = ntiles < 2 * v3d_num_cus() ? ntiles : 2 * v3d_num_cus();
-    V3D_LAUNCH(6, 192, 160, ntiles, (gemm_kernel_v6<192, 160, 3, V3D_GEMM_LINEAR>), dim3(grid), 256, st, p, ntiles);
+    V3D_LAUNCH(6, 192, 160, ntiles, (gemm_kernel_v6<192, 160, 3, MODE>), dim3(grid), 256, st, p, ntiles);
     return v3d_check_launch("v3d_gemm(v6)");
+}
+
+// Tile quantisation of the persistent kernels (round 6).  A launch of t tiles on G block slots idles (ceil(t / G) G - t) / G of its last round; the
+// 32 x 32 and 16 x 16 levels of the U-Net sit at 1.4 - 2.25 rounds of v3 tiles.  gemm_kernel_v6's 192 x 160 tiles on 512 slots halve the granule:
+// measured (profiles/r06_v6_ab.txt) -9 ... -14 % on the M = 9216 projections (N = 2560 / 3840) and the N = K = 640 linears, -5 % on the 32 x 32 temporal
+// convolution, a tie where v3's tiles fill >= 0.9 of their rounds or K = 2560 (v2 is as good there), +1 ... 6 % where v3 runs whole rounds (N = 320 at
+// 64 x 64, M = 36864 x N = 1280) - those stay where they were.  Also measured and dropped (same record): a SPLIT launch (v3 on the rows that make whole rounds,
+// the tail rows as a second launch on 192 x 160 / 96 x 160 tiles: +5 ... 8 % slower than either single launch - the second launch's ramp costs more than the
+// idle half round) and 192 x 128 tiles for N = 1280 at M = 9216 (480 tiles on 512 slots: +4 ... 18 % slower than v3's 192 tiles at 0.75 of a round).
+// returns -1 when the rule does not apply (the caller keeps its v3 / v2 path).  V3D_GEMM_V6: 0 = never, 1 = the rule (default), 2 = every legal launch (A/B knob)
+template <int MODE>
+int try_v6(const GP& p, hipStream_t st) {
+    const int v6 = v6_choice();
+    if (!v6 || impl_choice() != 0 || cfg_choice() >= 0 || p.K % 32 || p.K * 2 > 65536 || p.M % 192 || p.N % 160 || p.gn_stats || !e4_ok(p, 96, 80)) return -1;
+    const long long cus = v3d_num_cus(), slots = 2 * cus;
+    const bool v1 = p.N % 320 == 0;
+    const long long bm = v1 ? 192 : 256, bn = v1 ? 320 : 256;
+    const long long t3 = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), t6 = (p.M / 192) * (p.N / 160);
+    const double fill3 = (double)t3 / (double)(((t3 + cus - 1) / cus) * cus) * ((double)p.N / (double)(((p.N + bn - 1) / bn) * bn));
+    const double fill6 = (double)t6 / (double)(((t6 + slots - 1) / slots) * slots);
+    if (t6 >= slots && (v6 >= 2 || (p.K <= 1280 && fill3 < 0.9 && fill6 >= fill3))) return launch_v6<MODE>(p, st);
+    return -1;
 }
 
 template <int MODE, bool GEGLU>
 int dispatch(const GP& p, int batch, hipStream_t st) {
-    if constexpr (MODE == V3D_GEMM_LINEAR && !GEGLU) {
-        // v6 (192 x 160 tiles on two 4-wave blocks per CU) where the 192 x 320 / 256 x 256 tiles of v3 quantise badly on the CUs: measured
-        // (profiles/r06_v6_ab.txt) -9 ... -14 % on the M = 9216 projections and the N = K = 640 linears (1.4 - 2.25 rounds of v3 tiles), a tie where
-        // v3's tiles fill >= 0.9 of their rounds, +1 ... 6 % where v3 runs full rounds (N = 320 at 64 x 64, M = 36864 N = 1280) - those stay on v3.
-        const int v6 = v6_choice();
-        if (v6 && impl_choice() == 0 && cfg_choice() < 0 && batch == 1 && p.K % 32 == 0 && p.K * 2 <= 65536 && p.N % 160 == 0 && p.M % 192 == 0 && !p.gn_stats && e4_ok(p, 96, 80)) {
-            const long long cus = v3d_num_cus(), t6 = (p.M / 192) * (p.N / 160);
-            const bool v1 = p.N % 320 == 0;
-            const long long bm = v1 ? 192 : 256, bn = v1 ? 320 : 256;
-            const long long t3 = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-            const double fill3 = (double)t3 / (double)(((t3 + cus - 1) / cus) * cus) * ((double)p.N / (double)(((p.N + bn - 1) / bn) * bn));
-            const double fill6 = (double)t6 / (double)(((t6 + 2 * cus - 1) / (2 * cus)) * 2 * cus);
-            if (t6 >= V3D_GEMM_V6_MIN_TILES * cus / 256 && (v6 >= 2 || (p.K <= 1280 && fill3 < 0.9 && fill6 >= fill3))) return launch_v6(p, st);      // (K = 2560: a tie with v2)
+    if constexpr ((MODE == V3D_GEMM_LINEAR || MODE == V3D_GEMM_CONVT3) && !GEGLU) {
+        if (batch == 1) {
+            const int rc = try_v6<MODE>(p, st);
+            if (rc >= 0) return rc;
         }
     }
     // v3 (persistent big tiles) unless forced off (V3D_GEMM_IMPL=1/2), forced on (=3), or the tile count fills the CUs badly
@@ -1287,6 +1315,7 @@ int fill_params(const v3d_gemm_args* a, GP& p, int* halo) {
     p.halo_rows = a->mode == V3D_GEMM_CONVT3 ? a->halo_rows : 0;
     p.sA = a->sA; p.sW = a->sW; p.sO = a->sO;
     p.mt = p.nt = 0;
+    p.m_off = 0;
     {
         static int gm = -2, ti = -2;
         if (gm == -2) { const char* e = getenv("V3D_GEMM_GROUPM"); gm = e ? atoi(e) : -1; }      // -1 = heuristic, 0 / 1 = row-major walk, n = groups of n tile rows

@@ -35,6 +35,7 @@ struct V3dGemmParams {
     int T, tmin, tmax;
     long long S;
     long long halo_rows; // CONVT3 split-halo layout (0 = dense)
+    long long m_off;     // first output row of this launch (a launch over the row range [m_off, m_off + mt * BM) of the operation: gemm.hip split launches); M stays the operation's
     long long sA, sW, sO;
     int mt, nt;  // tile counts
     int group_m;         // tile walk: > 1 = ids run down groups of `group_m` tile rows first (L2-friendly patches), else row-major over N
