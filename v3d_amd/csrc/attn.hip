@@ -177,6 +177,16 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
 #ifndef ATTN_DEFER_MAX
 #define ATTN_DEFER_MAX 8
 #endif
+// round 6: the softmax loop is VALU-bound (per score and lane: v_fma 4 + v_exp_f32 16 + v_add 4 + v_max 4 + half a v_cvt_pk 2 = 30 cycles of the SIMD's
+// vector ALU against 16 cycles of its matrix pipe), so two of those go away:
+//   * Q is scaled by scale * log2(e) ONCE, when its fragments are loaded (re-rounded to bf16: 2^-9 relative per element, below the bf16 rounding of P),
+//     and the score accumulators start at -m_run instead of 0: the MFMAs deliver s' - m_run, and while the running maximum stands (the deferred
+//     maximum: nearly every tile after the first) the weight is a bare v_exp_f32 of the accumulator - no v_fma per score;
+//   * the tile maximum is gathered with v_max3_f32 (two scores per instruction).
+// A tile that raises the maximum by more than 2^ATTN_DEFER_MAX takes the wave-uniform slow path (one v_sub per score), as does tile 0.
+#ifndef ATTN_FUSE_MAX
+#define ATTN_FUSE_MAX 1
+#endif
 
 template <int QG>
 __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* __restrict__ q, long long ldq,
@@ -203,6 +213,18 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
 #pragma unroll
         for (int st = 0; st < 4; ++st)
             qf[g][st] = __builtin_bit_cast(bf16x8, buf_load16(rsQ, qrow < S ? (unsigned)((qrow * ldq + hi * 8 + st * 16) * 2) : kInvalid));
+    }
+    if (ATTN_FUSE_MAX) {      // scores come out of the MFMAs in the exp2 domain
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4 u = __builtin_bit_cast(u32x4, qf[g][st]);
+                u32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = pack2bf(bflo(u[e]) * scale2, bfhi(u[e]) * scale2);
+                qf[g][st] = __builtin_bit_cast(bf16x8, w);
+            }
     }
 
     // ---- LDS-DMA sources: piece = 8 rows x 128 B; lane l -> row (l >> 3), chunk position (l & 7), logical chunk pos ^ swz.
@@ -279,11 +301,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
         // ---- S^T = K . Q^T for both 32-key halves ----
         f32x16 sT[QG][2];
 #pragma unroll
-        for (int g = 0; g < QG; ++g)
+        for (int g = 0; g < QG; ++g) {
+            // (fused form: the accumulators start at -m_run, finite from tile 1 on)
+            const float init = (ATTN_FUSE_MAX && t > 0) ? -m_run[g] : 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sT[g][sub][r] = 0.f;
+                for (int r = 0; r < 16; ++r) sT[g][sub][r] = init;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -305,6 +330,49 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
                     for (int r = 0; r < 16; ++r)
                         if ((k0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7)) >= S) sT[g][sub][r] = -INFINITY;
         }
+        if (ATTN_FUSE_MAX) {
+            // sT = s' - base in the exp2 domain (base = m_run, 0 on tile 0).  d = what the running maximum grows by (0 while it stands)
+            float d[QG];
+            bool need_any = false;
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                float mx = fmaxf(sT[g][0][0], sT[g][1][0]);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sT[g][0][r]), sT[g][1][r]);        // (v_max3_f32)
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const bool need = (t == 0) || mx > (float)ATTN_DEFER_MAX;       // (every tile holds >= 1 valid key: mx is finite)
+                d[g] = need ? mx : 0.f;
+                alpha[g] = t == 0 ? 0.f : __builtin_amdgcn_exp2f(-d[g]);        // (tile 0: o = l = 0)
+                any_rescale |= need;
+                need_any |= need;
+                m_run[g] = (t == 0 ? 0.f : m_run[g]) + d[g];
+            }
+            const bool slow = __any(need_any);
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                float psum = 0.f;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    float pv[16];
+                    if (slow) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(sT[g][sub][r] - d[g]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(sT[g][sub][r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) psum += pv[r];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const u32x4 u = {pack2bf(pv[ks * 8 + 0], pv[ks * 8 + 1]), pack2bf(pv[ks * 8 + 2], pv[ks * 8 + 3]),
+                                         pack2bf(pv[ks * 8 + 4], pv[ks * 8 + 5]), pack2bf(pv[ks * 8 + 6], pv[ks * 8 + 7])};
+                        pf[g][sub][ks] = __builtin_bit_cast(bf16x8, u);
+                    }
+                }
+                l_run[g] = l_run[g] * alpha[g] + psum;
+            }
+        } else {
         // softmax in the exp2 domain on RAW scores: p = exp2(s * scale2 - m * scale2) is one v_fma + one bare v_exp_f32 per
         // score (libm's exp2f wraps every v_exp_f32 in a denormal-range compare / select / ldexp: ~6 extra VALU per score, and
         // the per-score scale multiply and -inf selects were another 3 - the loop was VALU-bound on them)
@@ -343,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
             }
             l_run[g] = l_run[g] * alpha[g] + psum;
             m_run[g] = m_new;
+        }
         }
         if (__any(any_rescale)) {
 #pragma unroll
