@@ -103,6 +103,15 @@ def build_cases(hip0, only):
     lin("lin_L2_1280_bar", 36 * 256, 1280, 1280, add=True, res=True, rpg=256)
     lin("lin_L2_ff2_br", 36 * 256, 1280, 5120, res=True)
     lin("lin_L2_qkv", 36 * 256, 3840, 1280, bias=False)
+    lin("lin_L3_1280_b", 36 * 64, 1280, 1280)
+    lin("lin_L3_1280_bar", 36 * 64, 1280, 1280, add=True, res=True, rpg=64)
+    lin("lin_L3_ff2_br", 36 * 64, 1280, 5120, res=True)
+    # one rank of an 8-way frame shard (3 frames x 2 samples = 6 images): BASELINE.json configs[2] / [3]
+    lin("shard6_L0_320_bar", 6 * 4096, 320, 320, add=True, res=True)
+    lin("shard6_L1_640_bar", 6 * 1024, 640, 640, add=True, res=True, rpg=1024)
+    lin("shard6_L1_ff2_br", 6 * 1024, 640, 2560, res=True)
+    lin("shard6_L2_1280_bar", 6 * 256, 1280, 1280, add=True, res=True, rpg=256)
+    lin("shard6_L2_ff2_br", 6 * 256, 1280, 5120, res=True)
     lin("geglu_L1", 36 * 1024, 5120, 640, geglu=True)
     lin("geglu_L2", 36 * 256, 10240, 1280, geglu=True)
     lin("lin_sq_4096", 4096, 4096, 4096)

@@ -1078,7 +1078,8 @@ int launch_v6(const GP& p0, hipStream_t st) {
 // convolution, a tie where v3's tiles fill >= 0.9 of their rounds or K = 2560 (v2 is as good there), +1 ... 6 % where v3 runs whole rounds (N = 320 at
 // 64 x 64, M = 36864 x N = 1280) - those stay where they were.  Also measured and dropped (same record): a SPLIT launch (v3 on the rows that make whole rounds,
 // the tail rows as a second launch on 192 x 160 / 96 x 160 tiles: +5 ... 8 % slower than either single launch - the second launch's ramp costs more than the
-// idle half round) and 192 x 128 tiles for N = 1280 at M = 9216 (480 tiles on 512 slots: +4 ... 18 % slower than v3's 192 tiles at 0.75 of a round).
+// idle half round), 192 x 128 tiles for N = 1280 at M = 9216 (480 tiles on 512 slots: +4 ... 18 % slower than v3's 192 tiles at 0.75 of a round), and 96 x 160 tiles for
+// launches whose v3 tiles cover half the CUs or fewer (the 8 x 8 level, the 4 - 6-image ranks of a frame shard: +-3 %, and 1.6x slower than split-K at K = 5120).
 // returns -1 when the rule does not apply (the caller keeps its v3 / v2 path).  V3D_GEMM_V6: 0 = never, 1 = the rule (default), 2 = every legal launch (A/B knob)
 template <int MODE>
 int try_v6(const GP& p, hipStream_t st) {
