@@ -635,6 +635,10 @@ def all_cases(full: bool = True):
         ("ln_proj_qkv_temporal", case_ln_proj, dict(M=128 * 5, N=960, n_rm=960, S=128, seed=1), TOL_BF16),
         ("ln_proj_all_transposed", case_ln_proj, dict(M=2 * 128, N=128, n_rm=0, S=128, seed=2), TOL_BF16),
         ("ln_proj_many_blocks", case_ln_proj, dict(M=128 * 700, N=960, n_rm=640, S=128 * 50, seed=3), TOL_BF16),
+        # round 6: the last round's row blocks cut into slab ranges (256 CUs: 288 row blocks = 1 round + 32 in 5 parts; 96 row blocks in 2 parts each; 350 = 1 + 94 in 2)
+        ("ln_proj_tail_5_parts", case_ln_proj, dict(M=256 * 288, N=960, n_rm=640, S=256 * 36, seed=4), TOL_BF16),
+        ("ln_proj_small_2_parts", case_ln_proj, dict(M=256 * 96, N=960, n_rm=640, S=256 * 24, seed=5), TOL_BF16),
+        ("ln_proj_tail_all_rowmajor", case_ln_proj, dict(M=256 * 320, N=960, n_rm=960, S=256 * 40, seed=6), TOL_BF16),
         ("ln_proj_8w_rowmajor", case_ln_proj, dict(M=256 * 300, N=960, n_rm=960, S=256, seed=4), TOL_BF16),
         ("fp8_quant_S256", case_attn_fp8, dict(n_img=2, S=256, heads=2, what="quant"), 7e-2),
         ("fp8_quant_S144_ragged", case_attn_fp8, dict(n_img=2, S=144, heads=1, what="quant"), 7e-2),

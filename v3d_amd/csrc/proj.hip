@@ -32,6 +32,10 @@ struct PP {
     int N, n_rm, Ct;
     unsigned w_bytes;
     float eps;
+    // work list (host: v3d_ln_proj): every block runs `full` whole row blocks (b, b + G, ...); the R = nblocks - full * G row blocks that are left are cut
+    // into `parts` slab ranges each (the output channels of a row block are independent: no reduction, the rows are simply loaded by `parts` blocks) and
+    // block b < R * parts takes range b % parts of row block full * G + b / parts.  parts = 1: the classic assignment (R <= G blocks take one more).
+    int full, tail_blocks, parts;
 };
 
 template <int I, int N, typename F>
@@ -92,16 +96,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
     // ---- weight stream: flat over (row block, slab); stream index j -> slab j % nslab, ring slot j % 3
     const bufrsrc_t rsW = make_rsrc(p.W, p.w_bytes);
     const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
-    const long long my_blocks = (nblocks - (long long)blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const long long total = my_blocks * nslab;
-    int ld_slab = 0, ld_slot = 0;
+    const int bid = (int)blockIdx.x;
+    const bool has_tail = bid < p.tail_blocks * p.parts;
+    const int tpart = has_tail ? bid % p.parts : 0;
+    const int ts0 = has_tail ? tpart * nslab / p.parts : 0, ts1 = has_tail ? (tpart + 1) * nslab / p.parts : 0;      // the tail item's slabs [ts0, ts1)
+    const long long tail_blk = (long long)p.full * gridDim.x + (has_tail ? bid / p.parts : 0);
+    const long long total = (long long)p.full * nslab + (ts1 - ts0);
+    (void)nblocks;
+    int ld_slab = p.full > 0 ? 0 : ts0, ld_slot = 0, ld_full_left = p.full;
     bool ld_live = true;
     auto issue_piece = [&](int i) __attribute__((always_inline)) {      // piece i of this wave's PPW pieces of the slab being loaded
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + ld_slot * SLAB + (wave + NW * i) * 1024), 16,
                                                  (int)(ld_live ? voff : kInvalid), ld_live ? ld_slab * SLAB + i * NW * 1024 : 0, 0, 0);
     };
     auto advance_load = [&]() __attribute__((always_inline)) {
-        ld_slab = (ld_slab + 1 == nslab) ? 0 : ld_slab + 1;
+        // the loader walks the consumer's slab sequence: 0 .. nslab - 1 per whole row block, then the tail item's range (past the end: harmless wrap-around)
+        if (++ld_slab == nslab && ld_full_left > 0) {
+            ld_slab = 0;
+            if (--ld_full_left == 0) ld_slab = ts0;
+        } else if (ld_slab >= nslab) {
+            ld_slab = 0;
+        }
         ld_slot = (ld_slot + 1 == NSLOT) ? 0 : ld_slot + 1;
     };
 
@@ -210,8 +225,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
     auto stamp = [&](int k) __attribute__((always_inline)) {
         if (DBG && blockIdx.x == 0 && j >= 16 && j < 48 && lane == 0) g_pj_dbg[(wave * 32 + (int)(j - 16)) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
-    int rd_slot = 0, sl = 0;
-    long long blk = blockIdx.x, row0 = 0, img = 0, pix0 = 0;
+    int rd_slot = 0, sl = p.full > 0 ? 0 : ts0, sl0 = sl, sl_end = p.full > 0 ? nslab : ts1, full_left = p.full;
+    long long blk = p.full > 0 ? (long long)blockIdx.x : tail_blk, row0 = 0, img = 0, pix0 = 0;
 
     // one slab: multiply slab `sl` of the current block (TRM: transposed output, MFMA operands swapped), push the previous tile (TRE) out
     auto iter = [&](auto trm_, auto tre_) __attribute__((always_inline)) {
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
         // after the pieces in iteration j - 2), and iteration j - 1's pieces and stores.  Around a block boundary (row loads in the queue,
         // no stores in the very first iteration) drain instead.
         stamp(0);
-        if (j < 3 || sl < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (j < 3 || sl - sl0 < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * NST) : "memory");
         stamp(1);
         __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone finished reading the slot refilled below
@@ -301,11 +316,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ln_proj_kernel(PP p) {
             else iter(std::true_type{}, std::true_type{});
         }
         p_row0 = row0; p_img = img; p_pix0 = pix0; p_sl = sl;
-        if (++sl == nslab) {
-            // the next block's rows come straight into the (now dead) fragment registers: the load latency is exposed once per block
-            sl = 0;
-            blk += gridDim.x;
-            if (blk < nblocks) begin_block();
+        if (++sl == sl_end) {
+            // the next item's rows come straight into the (now dead) fragment registers: the load latency is exposed once per item
+            if (--full_left > 0) {
+                sl = sl0 = 0;
+                blk += gridDim.x;
+                begin_block();
+            } else if (full_left == 0 && has_tail) {
+                sl = sl0 = ts0;
+                sl_end = ts1;
+                blk = tail_blk;
+                begin_block();
+            }
         }
     }
     // the last tile
@@ -352,7 +374,23 @@ extern "C" int v3d_ln_proj(const void* x, int64_t ldx, float eps, const void* Wp
     const bool big = cfg != 2 && M % 256 == 0 && (n_rm == N || S % 256 == 0);
     const long long nblocks = M / (big ? 256 : 128);
     const int cus = v3d_num_cus();
-    const int grid = nblocks < cus ? (int)nblocks : cus;
+    // work list: whole rounds of row blocks, then the remaining R row blocks cut into `parts` slab ranges each so that the last round is (nearly) as
+    // wide as the chip: M = 147456 at 256 rows = 576 row blocks = 2 rounds + 64 -> 4 parts of 3-4 of the 15 slabs instead of a third round a quarter
+    // full.  V3D_LNPROJ_SPLIT=0: the classic assignment (A/B knob).  At least 3 slabs per part (the rows are loaded and normalised once per part).
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("V3D_LNPROJ_SPLIT"); split = e ? atoi(e) : 1; }
+    int grid = nblocks < cus ? (int)nblocks : cus;
+    p.full = (int)(nblocks / grid);
+    p.tail_blocks = (int)(nblocks - (long long)p.full * grid);
+    p.parts = 1;
+    if (p.tail_blocks == 0 && p.full > 0) { p.full -= 1; p.tail_blocks = grid; }      // (uniform form: the last round is the "tail" of one whole part per block)
+    if (split && p.tail_blocks > 0) {
+        int parts = cus / p.tail_blocks, maxp = (N / 64) / 3;
+        if (parts > maxp) parts = maxp;
+        if (parts < 1) parts = 1;
+        p.parts = parts;
+        if (p.full == 0) grid = p.tail_blocks * parts;
+    }
     if (big && cfg == 0) {
         if (tl) hipLaunchKernelGGL((ln_proj_kernel<320, 4, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((ln_proj_kernel<320, 4, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
