@@ -49,7 +49,7 @@ PEAK_HBM_GBPS = 8000.0
 RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)      # 312.5: launches below it are HBM-bound (classified per launch)
 F_UNET_TFLOP = 45.677          # algorithmic FLOPs of one denoiser evaluation (reference graph, cfg batch 36)
 F_VAE_TFLOP_PER_FRAME = 3.043
-PMC_PROFILE = "r05_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
+PMC_PROFILE = "r06_pmc_traffic.json"     # profiles/<this>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
 
 T_FRAMES, STEPS, CFG, LAT = 18, 25, 4.5, 64
 P = "v3d_amd.sgm.modules.diffusionmodules."
@@ -377,10 +377,10 @@ def parity_rollout(device, lat=32):
     out = {"config": f"width 64, T=18, {lat}x{lat} latent, 25 EulerEDM steps, cfg 4.5, decode to {8 * lat}x{8 * lat}", "latent_cosine": round(cos, 6),
            "frames_psnr_db": round(10.0 * math.log10(peak * peak / mse), 2) if mse > 0 else None, "oracle_seconds": round(dt, 1)}
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_parity.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r06_parity.json")))
         r = rec["rollout_25_steps_width64"]
         out["recorded_64x64"] = {"latent_cosine": r["latent_cosine"], "frames_psnr_db": r["frames_psnr_db"], "decoder_only_psnr_db": r.get("decoder_only_psnr_db"),
-                                 "source": "profiles/r05_parity.json (written by tests/test_headline_parity_gpu.py on the GPU box)",
+                                 "source": "profiles/r06_parity.json (written by tests/test_headline_parity_gpu.py on the GPU box)",
                                  # round 5: the headline configuration itself against the REFERENCE's own modules (tests/golden/v3d_full.pt)
                                  "headline_width320_vs_reference_modules": rec.get("rollout_25_steps_width320_vs_reference"),
                                  "headline_evals_vs_reference_modules": [rec[k] for k in ("headline_eval_vs_reference_call0", "headline_eval_vs_reference_call8",

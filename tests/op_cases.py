@@ -186,6 +186,9 @@ def case_ff_fused(hip, emu, dev, *, M, C=320, hidden=1280, res=1, coef=False, se
         emu.ln_ff_fused(x, 1e-5, w1, b1, w2, b2, o_e, **kw)
         return compare(o_h, o_e)
     hip.ff_fused(x, w1, b1, w2, b2, o_h, **kw)
+    o_2 = torch.zeros_like(o_h)
+    hip.ff_fused(x, w1, b1, w2, b2, o_2, **kw)
+    assert torch.equal(o_h, o_2), "two identical v3d_ff_fused launches differ"
     emu.ff_fused(x, w1, b1, w2, b2, o_e, **kw)
     return compare(o_h, o_e)
 
@@ -554,6 +557,10 @@ def all_cases(full: bool = True):
         ("ln_ff_fused_res1", case_ff_fused, dict(M=384, res=1, ln=True, seed=4), TOL_BF16),
         ("ln_ff_fused_blend", case_ff_fused, dict(M=128 * 5, res=2, coef=True, ln=True, seed=5), TOL_BF16),
         ("ln_ff_fused_many_blocks", case_ff_fused, dict(M=128 * 600, res=1, ln=True, seed=6), TOL_BF16),
+        # (round 6: 1.25 rounds and 0.4 rounds of row blocks on 256 CUs - sizes a tail split along the hidden dimension was tried on; see tools/ff_rounds_probe.py)
+        ("ff_fused_partial_round", case_ff_fused, dict(M=128 * 320, res=2, coef=True, seed=7), TOL_BF16),
+        ("ln_ff_fused_partial_round", case_ff_fused, dict(M=128 * 320, res=1, ln=True, seed=8), TOL_BF16),
+        ("ff_fused_under_one_round", case_ff_fused, dict(M=128 * 100, res=1, seed=9), TOL_BF16),
         ("gemm_batched_perbatchW", case_gemm, dict(M=128, N=128, K=512, batch=2, bias=False, shared_w=False, out_fp32=True), TOL_BF16),
         ("conv3x3_small", case_gemm, dict(M=0, N=64, K=32, mode=C3, conv=(2, 8, 8, 1, 1)), TOL_BF16),
         ("conv3x3_odd_hw", case_gemm, dict(M=0, N=40, K=24, mode=C3, conv=(3, 7, 5, 1, 1), add=True, res=1), TOL_BF16),

@@ -80,6 +80,8 @@ def test_hip_tower_matches_independent_implementation(case, tol):
     with use_backend(HipOps()):
         got = emb(img.cuda())[:, 0].float().cpu()
     rel, cos = rel_cos(got, fx["image_embeds"])
+    from conftest import record_parity
+    record_parity(f"clip_tower_{case}_vs_transformers", {"max_rel_err": round(rel, 5), "cosine": round(cos, 6), "layers": fx["vision_cfg"]["layers"], "width": fx["vision_cfg"]["width"]})
     assert rel <= tol and cos >= 0.999, (case, rel, cos)
 
 
