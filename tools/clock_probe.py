@@ -1,6 +1,6 @@
-"""Is the chip power / clock limited at full occupancy?  (round 6)  The instrumented v3d_ff_fused build stamps s_memtime (shader cycles) per tick of block 0; the
-same launch is timed with HIP events.  cycles per row block / wall time per row block = the clock the CU held.  Run with few and with all CUs active:
-  V3D_FF_TIMELINE=1 python tools/clock_probe.py"""
+"""Which clock does the chip hold under full-occupancy MFMA load?  (round 6)  The instrumented v3d_ff_fused build stamps, at the top of every tick of block 0,
+s_memtime (shader cycles) AND s_memrealtime (a constant 100 MHz counter): cycles per tick / real time per tick = the shader clock, measured INSIDE the main loop
+(launch gaps, prologue and epilogue play no part).  Run with few and with all CUs active:   V3D_FF_TIMELINE=1 python tools/clock_probe.py"""
 import os, sys, math, ctypes
 os.environ.setdefault("V3D_FF_TIMELINE", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +37,8 @@ for ncu in (16, 64, 128, 256):
     buf = (ctypes.c_ulonglong * (4 * 16 * 8 + 4 * 4 * 8))()
     assert hip.lib.v3d_debug_ff_timeline(buf) == 0
     t = (np.array(buf[:], dtype=np.uint64) & np.uint64(0x7fffffffffffffff)).astype(np.int64)[:512].reshape(4, 16, 8)
-    tick = float(np.diff(t[0, 2:14, 0]).mean())              # cycles per tick (wave 0, ticks 10 .. 21 of the only row block of block 0)
-    print(f"{ncu:4d} CUs active: {wall:7.1f} us per one-row-block launch, {tick:7.0f} cycles per tick x 41 ticks = {tick * 41 / 1e3:6.1f} k cycles per row block "
-          f"-> {tick * 41 / wall / 1e3:5.2f} GHz if the launch were all ticks", flush=True)
+    tick = float(np.diff(t[0, 2:14, 0]).mean())              # shader cycles per tick (wave 0, ticks 10 .. 21 of the only row block of block 0)
+    real = float(np.diff(t[0, 2:14, 7]).mean())              # 100 MHz ticks per tick
+    ghz = tick / (real * 10.0) if real > 0 else float("nan")  # cycles / ns
+    print(f"{ncu:4d} CUs active: {wall:7.1f} us per one-row-block launch; inside the main loop {tick:7.0f} shader cycles = {real * 10:7.0f} ns per tick -> {ghz:5.3f} GHz; "
+          f"bf16 dense peak at that clock {256 * 4 * 1024 * ghz / 1e3:6.0f} TFLOP/s", flush=True)

@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(FFP p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
     unsigned long long* dbg = g_ff_dbg;   // timeline build: stamps go straight to global memory (no LDS left: 159.3 of 160 KiB are in use)
     auto stamp = [&](int s_, int k) __attribute__((always_inline)) {
-        if (DBG && ((FF_STAMPS >> k) & 1) && blockIdx.x == 0 && s_ >= 8 && s_ < 24 && (threadIdx.x & 63) == 0) dbg[((threadIdx.x >> 6) * 16 + (s_ - 8)) * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (DBG && ((FF_STAMPS >> k) & 1) && blockIdx.x == 0 && s_ >= 8 && s_ < 24 && (threadIdx.x & 63) == 0) {
+            dbg[((threadIdx.x >> 6) * 16 + (s_ - 8)) * 8 + k] = __builtin_amdgcn_s_memtime();
+            // slot 7: the constant-rate counter (100 MHz) at the tick top - shader cycles per tick / real time per tick = the clock the CU holds (tools/clock_probe.py)
+            if (k == 0) dbg[((threadIdx.x >> 6) * 16 + (s_ - 8)) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        }
     };
 
     int bcount = 0;
