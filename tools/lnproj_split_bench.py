@@ -1,3 +1,4 @@
+"""v3d_ln_proj at the 64 x 64 level and at shard-rank sizes with and without the tail split (V3D_LNPROJ_SPLIT=0/1, read once per process)."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import torch
