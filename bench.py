@@ -284,6 +284,10 @@ def measure_rooflines(step):
             "algorithmic_tflop_per_sample": round(flops / 1e12, 2), "gemm_ms_per_sample": round(tot_ms, 2),
             "timed_ms_per_sample_all_families": round(sum(v[0] for v in fam.values()), 2),
             "measured_on": "one extra instrumented sample after the timed region (HIP events per launch, csrc " + csrc_digest() + ")",
+            # context, not the contract's `frac`: the shader clock measured inside a full-occupancy MFMA main loop on this chip (tools/clock_probe.py:
+            # s_memtime against the 100 MHz s_memrealtime) is 1.77 GHz with all 256 CUs busy (2.41 GHz with 16) - `peak` above is the 2.4 GHz figure
+            "sustained_clock_context": {"ghz_all_cus_busy": 1.773, "ghz_16_cus_busy": 2.407, "bf16_dense_peak_at_that_clock_tflops": 1859.0,
+                                        "frac_of_that": round(achieved / 1859.0, 4), "source": "profiles/r06_clock_probe.txt (recorded; not re-measured by bench.py)"},
             "per_kernel": per}
 
 
