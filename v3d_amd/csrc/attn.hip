@@ -1,6 +1,8 @@
 // Attention kernels for gfx950: spatial (streamed-softmax MFMA, d_head 64) and temporal (T <= 32 frames).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -187,6 +189,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const bf16_t* __re
 #ifndef ATTN_FUSE_MAX
 #define ATTN_FUSE_MAX 1
 #endif
+// round 6: inside a tile the P.V MFMAs of the first 32-key half run beside the exponentials of the second half (one scheduling region, the interleave fixed with
+// sched_group_barrier: a wave's own MFMAs hide a few VALU / transcendental issues each) instead of "all exponentials, then all MFMAs".  Same arithmetic, same order
+// of every accumulation: bit-identical results.  0 = the sequential form (A/B).
+#ifndef ATTN_PIPE
+#define ATTN_PIPE 1
+#endif
 
 template <int QG>
 __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* __restrict__ q, long long ldq,
@@ -348,6 +356,58 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_v2_kernel(const bf16_t* _
                 m_run[g] = (t == 0 ? 0.f : m_run[g]) + d[g];
             }
             const bool slow = __any(need_any);
+            if (ATTN_PIPE && !slow) {
+                // fast path (the running maxima stand: alpha = 1, no rescale): weights of half 0, then { P.V of half 0 | weights of half 1 }, then P.V of half 1
+                float psum[QG];
+                auto weights = [&](auto sub_) __attribute__((always_inline)) {
+                    constexpr int sub = decltype(sub_)::value;
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        float pv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(sT[g][sub][r]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) psum[g] += pv[r];
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const u32x4 u = {pack2bf(pv[ks * 8 + 0], pv[ks * 8 + 1]), pack2bf(pv[ks * 8 + 2], pv[ks * 8 + 3]),
+                                             pack2bf(pv[ks * 8 + 4], pv[ks * 8 + 5]), pack2bf(pv[ks * 8 + 6], pv[ks * 8 + 7])};
+                            pf[g][sub][ks] = __builtin_bit_cast(bf16x8, u);
+                        }
+                    }
+                };
+                auto pv_half = [&](auto sub_) __attribute__((always_inline)) {
+                    constexpr int sub = decltype(sub_)::value;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int ch = ((sub * 4 + ks * 2 + hi) ^ vsw) * 16;
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sb + voff[db] + ch);
+#pragma unroll
+                            for (int g = 0; g < QG; ++g) o[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][sub][ks], o[g][db], 0, 0, 0);
+                        }
+                    }
+                };
+#pragma unroll
+                for (int g = 0; g < QG; ++g) psum[g] = 0.f;
+                weights(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                pv_half(std::integral_constant<int, 0>{});
+                weights(std::integral_constant<int, 1>{});
+                // 4 QG MFMAs beside 16 QG exponentials + 16 QG adds + 8 QG conversions: one MFMA, (every other one) a V^T fragment read, then its share of the vector work
+#pragma unroll
+                for (int i = 0; i < 4 * QG; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i % QG == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 10, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                pv_half(std::integral_constant<int, 1>{});
+#pragma unroll
+                for (int g = 0; g < QG; ++g) l_run[g] += psum[g];
+                continue;
+            }
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 float psum = 0.f;
