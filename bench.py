@@ -432,11 +432,13 @@ def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
         s2, s6 = sampler_of(2), sampler_of(6)
         extra = {"image_only_indicator": torch.zeros(2 * B_IN, T_FRAMES, device=device), "num_video_frames": T_FRAMES}
 
+        dec_local = (lambda z: dec(z * (1.0 / 0.18215), timesteps=sh.T_local)) if sh is not None else None      # (one object per rank: the graph cache keys on shapes)
+
         def sample(smp):
             if sh is None:
                 z = smp(lambda i, sg, cc: denoiser(wrapped, i, sg, cc, **extra), noise.clone(), cond=c, uc=uc) * (1.0 / 0.18215)
                 return torch.cat([dec(z[i:i + T_FRAMES], timesteps=T_FRAMES) for i in range(0, z.shape[0], T_FRAMES)], dim=0)      # (as make_step: one input at a time)
-            return sharded_sample(sh, smp, denoiser, wrapped, lambda z: dec(z * (1.0 / 0.18215), timesteps=sh.T_local), noise.clone(), c, uc, B=B_IN, gather=False)
+            return sharded_sample(sh, smp, denoiser, wrapped, dec_local, noise.clone(), c, uc, B=B_IN, gather=False, graph=bool(args.graph))
 
         t2, t6 = wall(lambda: sample(s2)), wall(lambda: sample(s6))
         ev = (t6 - t2) / 4.0
@@ -486,6 +488,7 @@ def shard_sim(args, device, unet, wrapped, dec, denoiser, noise, c, uc):
     return {"world": N, "cus": cus, "unsharded": base, "rank_0": r_first, f"rank_{N - 1}": r_last,
             "ideal_speedup_most_loaded_rank": round(T_FRAMES / r_first["frames"], 2),
             "compute_only_strong_scaling_ceiling": round(base["ms_per_sample_compute_only"] / slow, 2),
+            "hip_graph_replay_of_the_rank": bool(args.graph),
             "note": "compute of one rank on one GPU with self-fed halos / K|V / statistics (v3d_amd/dist.py SimFrameShard); communication is NOT timed - "
                     "no RCCL run of this path exists (one GPU per build box)"}
 

@@ -391,7 +391,7 @@ def local_sampler(sampler, shard: FrameShard):
 
 
 def sharded_sample(shard: FrameShard, sampler, denoiser, network, decode, noise, c: dict, uc: dict, *, B: int = 1,
-                   image_only_indicator: Optional[torch.Tensor] = None, gather: bool = True):
+                   image_only_indicator: Optional[torch.Tensor] = None, gather: bool = True, graph: bool = False):
     """One sample (B inputs x T_global frames) with the frame axis sharded for the WHOLE path: every rank keeps its frames of the
     sampler state x for all steps (denoiser evaluations exchange K|V, halo frames and GroupNorm sums inside the U-Net), decodes its
     own frames (VideoDecoder: halos + GroupNorm sums again) and only the decoded frames are gathered.
@@ -432,6 +432,18 @@ def sharded_sample(shard: FrameShard, sampler, denoiser, network, decode, noise,
 
         def den(inp, sigma, cc):
             return denoiser(network, inp, sigma, cc, **extra)
+    if graph:
+        # HIP-graph replay of the rank's evaluation and decode (engine/graph.py), cached on the shard (one capture per shape).  Measured (bench.py --shard-sim 8
+        # --graph, profiles/r06_shard_sim8_graph.log): a rank of an 8-way shard runs ~600 kernels on 4-6 images per evaluation in 20.4 / 18.6 ms (3 / 2 frames)
+        # against 20.1 / 21.2 ms eager - the rank is NOT bound by the host's launch rate but by the fixed cost of 600 small kernels on the GPU itself (~33 us each:
+        # persistent-kernel prologues, pipeline fill, partial rounds); compute-only ceiling 2.78x vs 2.66x.  SimFrameShard only (self-fed device copies): under a
+        # real FrameShard the grouped point-to-point calls would have to be captured too (torch.cuda.graph + NCCL capture) - untested, one GPU per build box.
+        from .engine.graph import graphed
+        cache = shard.__dict__.setdefault("_graphed", {})
+        key = (id(network), id(denoiser), B, Tl, isinstance(shard, HybridShard))
+        if key not in cache:
+            cache[key] = (graphed(den, enabled=True), graphed(decode, enabled=True))
+        den, decode = cache[key]
     with shard.activate(context_frame0=ctx0):
         z = smp(den, x, cond=c_loc, uc=uc_loc)
         frames = decode(z)
