@@ -97,6 +97,9 @@ def build_cases(hip0, only):
     # linears (v3 192 x 320 / v2), attention + feed-forward projections
     lin("lin_L0_320_bar", 36 * 4096, 320, 320, add=True, res=True)
     lin("lin_L0_320_b", 36 * 4096, 320, 320)
+    lin("lin_L0_320_r", 36 * 4096, 320, 320, res=True)
+    lin("lin_L0_skip640_b", 36 * 4096, 320, 640)                               # K = 640 -> 320 (skip connection of the concat ResBlocks)
+    lin("lin_L0_skip640_bar", 36 * 4096, 320, 640, add=True, res=True)
     lin("lin_L1_640_bar", 36 * 1024, 640, 640, add=True, res=True, rpg=1024)
     lin("lin_L1_ff2_br", 36 * 1024, 640, 2560, res=True)
     lin("lin_L1_qkv", 36 * 1024, 1920, 640, bias=False)

@@ -21,7 +21,12 @@
 // its 2 x 94 MB of HBM traffic per use disappear.
 #include <stdlib.h>
 
+#define E4_ASM_READS 0        // this file chooses the epilogue's LDS read form per kernel (CONV_TEMP_READS below); gn_flush keeps the compiler-visible reads
 #include "gemm_common.h"
+
+#ifndef CONV_TEMP_READS
+#define CONV_TEMP_READS 2      // e4_fragment read form of the temporal haloed kernels (A/B: -DCONV_TEMP_READS=0)
+#endif
 
 // Timing experiments (tools/conv_ablate.sh, results in profiles/r03_conv_ablation.txt): -DCONV_ABL=<bits> builds of this file only -
 // compile-time, so the measured loop carries no extra branches.  1 no epilogue, 2 no MFMA, 4 no weight DMA, 4096 no fragment reads,
@@ -570,7 +575,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             asm volatile("" : "+v"(lane_e));
             const SkItem done = item_at(it);          // (re-read: role / donors are not carried through the chunk loop)
             if (done.role == 2) sk_gather<MF, NF>(p, acc, done.d0, done.d1, wave, lane_e, Gd);
-            e4_retire_tile<MF, NF, GN>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
+            // staging reads of the epilogue (gemm_common.h e4_fragment RD): the temporal kernels take the lean asm form; the 3 x 3 kernels sit at 256 registers and
+            // spill inside their main loops with either asm form (tools/check_loop_scratch.py) - they keep the compiler-visible reads and their vmcnt(0) drains
+            e4_retire_tile<MF, NF, GN, E4_DEPTH, (HM == HM_TEMP ? CONV_TEMP_READS : 0)>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)

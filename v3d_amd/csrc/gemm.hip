@@ -1097,6 +1097,16 @@ int try_v6(const GP& p, hipStream_t st) {
 
 template <int MODE, bool GEGLU>
 int dispatch(const GP& p, int batch, hipStream_t st) {
+#ifdef V3D_EXPERIMENTS
+    if constexpr (MODE == V3D_GEMM_LINEAR && !GEGLU) {
+        static int v7 = -1;
+        if (v7 < 0) {
+            const char* e = getenv("V3D_GEMM_V7");
+            v7 = e ? atoi(e) : 0;
+        }
+        if (v7 && batch == 1 && v3d_gemm_v7_variant(p, MODE)) return v3d_gemm_v7_launch(p, (void*)st);
+    }
+#endif
     if constexpr ((MODE == V3D_GEMM_LINEAR || MODE == V3D_GEMM_CONVT3) && !GEGLU) {
         if (batch == 1) {
             const int rc = try_v6<MODE>(p, st);

@@ -6,6 +6,12 @@
 
 #include "common.h"
 
+// LDS reads of the hand-managed epilogue (e4_fragment, gn_flush) as inline asm: 0 compiler-visible reads, 1 batched asm reads, 2 one piece per LDS round trip
+// (see e4_lds_read8 below for why; e4_fragment takes the form as its template parameter RD, this is its default)
+#ifndef E4_ASM_READS
+#define E4_ASM_READS 1
+#endif
+
 // Experiment switches (skip epilogue / MFMAs / DMA / stores, slot timelines) exist only in builds made with -DV3D_EXPERIMENTS
 // (tools/gemm_floor.py, tools/v3_timeline.py say how); the shipped library has no environment variable that changes results.
 #ifdef V3D_EXPERIMENTS
@@ -81,6 +87,9 @@ int v3d_gemm_v4_launch(const V3dGemmParams& p, int mode, int variant, void* stre
 // tools/lab/gemm5.hip: the same structure on v_mfma_f32_32x32x16_bf16 (round 6, V3D_GEMM_V5=1)
 int v3d_gemm_v5_variant(const V3dGemmParams& p, int mode, int v3_variant);
 int v3d_gemm_v5_launch(const V3dGemmParams& p, int mode, int variant, void* stream);
+// tools/lab/gemm7.hip: N = 320, K = 320 / 640 linears with a deferred epilogue (round 6, V3D_GEMM_V7=1)
+int v3d_gemm_v7_variant(const V3dGemmParams& p, int mode);
+int v3d_gemm_v7_launch(const V3dGemmParams& p, void* stream);
 #endif
 // gemm.hip: stream-K plan of a persistent launch (fills p.sk_*, returns the grid): ntiles tiles of `units` split granules on the device's CUs;
 // slot_bytes = one block's accumulators in fp32.  Leaves the classic assignment (sk_tail = 0) when the tail round is full enough or too thin.
@@ -295,9 +304,17 @@ __device__ __forceinline__ void gn_flush(const GP& p, GnAcc<NF>& a, long long si
         const int c1 = (g + 1) * cpg - (int)nw0 < NF * 16 ? (g + 1) * cpg - (int)nw0 : NF * 16;
         float sa = 0.f, sb = 0.f;
         for (int cp = c0 >> 1; cp < (c1 >> 1); ++cp) {            // channel pair cp = channels 2 cp, 2 cp + 1 of the tile
+#if E4_ASM_READS
+            // (asm reads + an asm wait that names them: a ds_read the compiler can see gets s_waitcnt vmcnt(0) in front of it while LDS-DMA is in flight)
+            const unsigned ea = lds_addr(sf + (cp >> 1) * 4 + (cp & 1));
+            float e0, e2;
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(e0), "=&v"(e2) : "v"(ea) : "memory");
+#else
             const float* e = sf + (cp >> 1) * 4 + (cp & 1);
-            sa += e[0];
-            sb += e[2];
+            const float e0 = e[0], e2 = e[2];
+#endif
+            sa += e0;
+            sb += e2;
         }
         float* dst = p.gn_stats + ((sid * p.gn_nslots + slot) * 32 + g) * 2;
         *reinterpret_cast<float2*>(dst) = make_float2(sa, sb);
@@ -649,6 +666,13 @@ __device__ __forceinline__ void e4_tile_consts(const GP& p, long long m0f, long 
     t.c1 = cf1;
     t.c2 = cf2;
 }
+// LDS READS of the staging rows as inline asm too (round 6).  With LDS-DMA in flight hipcc answers every ds_read IT can see in this code with s_waitcnt vmcnt(0)
+// (it cannot tell the wave-private staging rows from the ring the DMA writes): five per fragment in front of the residual reads and three in front of the row reads -
+// each a full drain of the wave's stores, look-ahead residual loads and ring prefetches, i.e. the memory round trip per fragment the round-6 timeline shows
+// (profiles/r06_timeline_k320_bar.txt: 5.5 k cycles per fragment).  Rounds 3-5 believed this path wait-free; the disassembly has 61 vmcnt(0) per kernel.
+// The asm reads are followed by an asm lgkmcnt(0) that NAMES their destinations (the compiler neither counts them nor may touch the registers before it).
+__device__ __forceinline__ void e4_lds_read8(u32x2& dst, unsigned addr) { asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void e4_lds_read16(u32x4& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
 __device__ __forceinline__ void e4_lds_write16(unsigned addr, u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void e4_lds_write8(unsigned addr, uint32_t w0, uint32_t w1) {
     const u32x2 v = {w0, w1};
@@ -660,8 +684,9 @@ __device__ __forceinline__ void e4_lds_write8(unsigned addr, uint32_t w0, uint32
 // output rows will stand, every lane reads its own 8 bytes per fragment column, adds, and writes the bf16 result back to the same 8 bytes
 // (4 live floats per column instead of the whole fragment).  NOTHING here waits for a store: the rows leave as plain 16-byte stores that
 // drain while the next fragments are computed (round 3 waited vmcnt(0) once per fragment: the previous fragment's stores and the next
-// fragment's residual loads - 6 serialised memory round trips per wave tile with every CU of the chip in the same phase).
-template <int NF, bool GN>
+// fragment's residual loads - 6 serialised memory round trips per wave tile with every CU of the chip in the same phase).  That sentence became
+// true in round 6 only, with RD != 0: until then the compiler put its own vmcnt(0) in front of every staging read (see e4_lds_read8).
+template <int NF, bool GN, int RD = E4_ASM_READS>
 __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long long m0f, long long nw0, int lane, unsigned char* stage, const E4Res& cur,
                                             const E4Tile<NF>& t, GnAcc<GN ? NF : 1>& gn) {
     constexpr int CPRO = NF * 2, NP = 16 * CPRO, SROW = NF * 32 + 16;
@@ -696,6 +721,63 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
         else
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3])::"memory");
     }
+    if constexpr (RD != 0) {
+    // E4_ASM_READS 1: the fragment's NF residual pieces in one LDS round trip (2 NF registers); 2: one piece per round trip (2 registers: the LDS-haloed kernels
+    // of conv.hip sit at 256 registers and spill inside their main loops with the batched form)
+    u32x2 rr[RD == 1 ? NF : 1];
+#pragma unroll
+    for (int j = 0; j < (RD == 1 ? NF : 1); ++j) rr[j] = u32x2{0u, 0u};
+    if (has1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (RD == 1) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) e4_lds_read8(rr[j], mine + j * 32);
+            static_assert(NF == 4 || NF == 5, "e4: 64- or 80-channel wave tiles");
+            if constexpr (NF == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]), "+v"(rr[RD == 1 ? 4 : 0])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3])::"memory");
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (acc[j][r] + t.ba[j][r]) * t.ca;
+        if (has1) {
+            const int jr = RD == 1 ? j : 0;
+            if constexpr (RD != 1) {
+                e4_lds_read8(rr[0], mine + j * 32);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[0])::"memory");
+            }
+            o[0] += t.c1 * bflo(rr[jr][0]); o[1] += t.c1 * bfhi(rr[jr][0]); o[2] += t.c1 * bflo(rr[jr][1]); o[3] += t.c1 * bfhi(rr[jr][1]);
+        }
+        if (has2) {
+            o[0] += t.c2 * bflo(q2[j][0]); o[1] += t.c2 * bfhi(q2[j][0]); o[2] += t.c2 * bflo(q2[j][1]); o[3] += t.c2 * bfhi(q2[j][1]);
+        }
+        const uint32_t w0 = pack2bf(o[0], o[1]), w1 = pack2bf(o[2], o[3]);
+        e4_lds_write8(mine + j * 32, w0, w1);
+        if constexpr (GN) {
+            gn_add_pair(gn.s[j][0], gn.q[j][0], w0);
+            gn_add_pair(gn.s[j][1], gn.q[j][1], w1);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16_t* outz = reinterpret_cast<bf16_t*>(p.out) + m0f * p.ldo + nw0;
+    constexpr int NK = (NP + 63) / 64;
+    static_assert(NK == 2 || NK == 3, "row pieces per lane");
+    // (one piece at a time: three in flight cost 8 more registers, and the LDS-haloed kernels have none to spare - their main loops spilled)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int c = k * 64 + lane;
+        int cr = c;
+        if (NP % 64 != 0 && cr >= NP) cr = lane;                   // (lanes past the grid read a valid address; the value is not stored)
+        u32x4 sr;
+        e4_lds_read16(sr, sbase + (unsigned)((cr / CPRO) * SROW + (cr % CPRO) * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sr)::"memory");
+        const int row = c / CPRO, ch = c % CPRO;
+        if ((NP % 64 == 0 || c < NP) && !V3D_ABL(p, 1)) *reinterpret_cast<u32x4*>(outz + (long long)row * p.ldo + ch * 8) = sr;
+    }
+    } else {
+    // (RD = 0: compiler-visible reads - the 3 x 3 LDS-haloed kernels of conv.hip sit at 256 registers and spill inside their main loops with either asm form)
     if (has1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
@@ -723,6 +805,7 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
         const int c = k * 64 + lane;
         const int row = c / CPRO, ch = c % CPRO;
         if ((NP % 64 == 0 || c < NP) && !V3D_ABL(p, 1)) *reinterpret_cast<uint4*>(outz + (long long)row * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * SROW + ch * 16);
+    }
     }
 }
 
@@ -783,7 +866,7 @@ struct E4AccArray {
         for (int j = 0; j < NF; ++j) out[j] = a[F][j];
     }
 };
-template <int F, int MF, int NF, bool GN, int D, typename Acc, typename RowFn, typename FlushFn>
+template <int F, int MF, int NF, bool GN, int D, int RD, typename Acc, typename RowFn, typename FlushFn>
 __device__ __forceinline__ void e4_retire(const GP& p, const Acc& acc, long long nw0, int lane, unsigned char* stage, E4Res cur, E4Res n1, E4Res n2,
                                           E4Tile<NF> t, GnAcc<GN ? NF : 1>& gn, RowFn rowfn, FlushFn flushfn) {
     if constexpr (F < MF) {
@@ -816,16 +899,16 @@ __device__ __forceinline__ void e4_retire(const GP& p, const Acc& acc, long long
         {
             f32x4 accf[NF];
             acc.template get<F>(accf);
-            e4_fragment<NF, GN>(p, accf, m0f, nw0, lane, stage, cur, t, gn);
+            e4_fragment<NF, GN, RD>(p, accf, m0f, nw0, lane, stage, cur, t, gn);
         }
         if constexpr (GN) {
             unsigned slot = 0, sid = 0;
             if (flushfn(F, m0f, slot, sid)) gn_flush<NF>(p, gn, (long long)sid, nw0, lane, stage, slot);
         }
-        e4_retire<F + 1, MF, NF, GN, D>(p, acc, nw0, lane, stage, n1, n2, n3, t, gn, rowfn, flushfn);
+        e4_retire<F + 1, MF, NF, GN, D, RD>(p, acc, nw0, lane, stage, n1, n2, n3, t, gn, rowfn, flushfn);
     }
 }
-template <int MF, int NF, bool GN, int D = E4_DEPTH, typename Acc, typename RowFn, typename FlushFn>
+template <int MF, int NF, bool GN, int D = E4_DEPTH, int RD = E4_ASM_READS, typename Acc, typename RowFn, typename FlushFn>
 __device__ __forceinline__ void e4_retire_tile_src(const GP& p, const Acc& acc, long long nw0, int lane, unsigned char* stage, RowFn rowfn, FlushFn flushfn) {
     E4Res r0, r1, r2;
     r0.a0 = r0.a1 = r0.a2 = u32x4{0u, 0u, 0u, 0u};
@@ -841,11 +924,11 @@ __device__ __forceinline__ void e4_retire_tile_src(const GP& p, const Acc& acc, 
     asm volatile("" : "+v"(r0.a0), "+v"(r0.a1), "+v"(r0.a2), "+v"(r1.a0), "+v"(r1.a1), "+v"(r1.a2), "+v"(r2.a0), "+v"(r2.a1), "+v"(r2.a2));
     GnAcc<GN ? NF : 1> gn;
     if constexpr (GN) gn_zero(gn);
-    e4_retire<0, MF, NF, GN, D>(p, acc, nw0, lane, stage, r0, r1, r2, t, gn, rowfn, flushfn);
+    e4_retire<0, MF, NF, GN, D, RD>(p, acc, nw0, lane, stage, r0, r1, r2, t, gn, rowfn, flushfn);
 }
-template <int MF, int NF, bool GN, int D = E4_DEPTH, typename RowFn, typename FlushFn>
+template <int MF, int NF, bool GN, int D = E4_DEPTH, int RD = E4_ASM_READS, typename RowFn, typename FlushFn>
 __device__ __forceinline__ void e4_retire_tile(const GP& p, f32x4 (&acc)[MF][NF], long long nw0, int lane, unsigned char* stage, RowFn rowfn, FlushFn flushfn) {
-    e4_retire_tile_src<MF, NF, GN, D>(p, E4AccArray<MF, NF>{acc}, nw0, lane, stage, rowfn, flushfn);
+    e4_retire_tile_src<MF, NF, GN, D, RD>(p, E4AccArray<MF, NF>{acc}, nw0, lane, stage, rowfn, flushfn);
 }
 
 // ---- stream-K tail ------------------------------------------------------------------------------------------------------------------------
