@@ -871,6 +871,9 @@ __device__ __forceinline__ void e4_retire(const GP& p, const Acc& acc, long long
                                           E4Tile<NF> t, GnAcc<GN ? NF : 1>& gn, RowFn rowfn, FlushFn flushfn) {
     if constexpr (F < MF) {
         static_assert(D >= 1 && D <= 3, "residual look-ahead: 1..3 fragments");
+        // depth 3 needs the compiler-visible reads (RD = 0): without their drains the register allocator's copies of the rotating piece sets (cur <- n1 <- n2 <- n3) read
+        // registers whose asm load is still in flight - wrong results in profiles/r06_e4_asm_reads_ab.txt, found by tools/check_inflight_regs.py; depths 1 and 2 are clean
+        static_assert(D <= 2 || RD == 0, "e4: look-ahead depth 3 only with compiler-visible staging reads");
         const long long m0f = rowfn(F);
         const bool has1 = p.res1 != nullptr;
         E4Res n3 = n2;
