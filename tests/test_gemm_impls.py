@@ -23,3 +23,14 @@ def test_gemm_parity_with_forced_impl(impl, extra):
         import re
         m = re.search(r"gn epilogue launches: (\d+)", r.stdout)
         assert m and int(m.group(1)) >= 5, r.stdout
+
+
+@pytest.mark.gpu
+def test_counted_waits_hold_under_memory_contention():
+    """The hand-managed epilogue (gemm_common.h e4_*) paces residual loads and row stores with COUNTED s_waitcnt and, since round 6, reads its staging rows with
+    inline asm so that the compiler adds no vmcnt(0) of its own: a wrong count now shows as a rare wrong row.  tools/e4_stress.py launches the persistent
+    LINEAR / two-blocks-per-CU / LDS-haloed kernels 60 times each into a poisoned output, every other launch against a 0.5-GB copy on a second stream, and
+    compares every result bit for bit with the first."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e4_stress.py"), "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 differ from the first") >= 10, r.stdout + r.stderr

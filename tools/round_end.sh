@@ -19,6 +19,7 @@ timeout 200 python tools/op_times.py > gpurun_out/${TAG}_op_times.log 2>&1
 timeout 200 python tools/conv_gn_bench.py > gpurun_out/${TAG}_conv_gn_bench.log 2>&1
 timeout 400 python bench.py --shard-sim 8 --inputs 4 --edm-steps 50 > gpurun_out/${TAG}_shard_sim8_inputs4_steps50.log 2>&1
 timeout 200 python tools/lib_gemm_probe.py > gpurun_out/${TAG}_lib_gemm_probe.log 2>&1
+timeout 600 python tools/e4_stress.py 2000 > gpurun_out/${TAG}_e4_stress.log 2>&1
 T0=$(date +%s)
 timeout 1200 python -m pytest tests -m gpu -q --durations=12 > gpurun_out/${TAG}_pytest_gpu.log 2>&1      # (1200 s = the driver's own limit for this suite)
 RC=$?
