@@ -16,6 +16,8 @@
 // (tools/gemm_floor.py, tools/v3_timeline.py say how); the shipped library has no environment variable that changes results.
 #ifdef V3D_EXPERIMENTS
 #define V3D_ABL(p, bit) ((p).ablate & (bit))
+#elif defined(V3D_ABL_STATIC)      // A/B builds only (tools/build_variant.sh <tag> "-DV3D_ABL_STATIC=<bits>"): the same switches at compile time - no branch in the measured code
+#define V3D_ABL(p, bit) ((V3D_ABL_STATIC) & (bit))
 #else
 #define V3D_ABL(p, bit) (0)
 #endif
