@@ -604,7 +604,12 @@ def all_cases(full: bool = True):
         ("conv_gn_16_streamk_many_donors", case_conv_gn, dict(N=320, C1=1280, conv=(36, 16, 16), res=1, gn_out=True, seed=10, expect_streamk=True), TOL_BF16),
         ("conv_gn_64_offcentre", case_conv_gn, dict(N=320, C1=64, conv=(3, 64, 64), mean=30.0, seed=5), TOL_BF16),
         ("conv_gn_nosilu", case_conv_gn, dict(N=320, C1=32, conv=(3, 32, 32), silu=False, seed=6, expect_fused=False), TOL_BF16),
-        ("conv_gn_unsupported_8x8", case_conv_gn, dict(N=1280, C1=64, conv=(36, 8, 8), expect_fused=False), TOL_BF16),
+        # W = 8 (round 6): three whole 8 x 8 images per tile, two image lines per fragment, up to three statistics groups per halo, stream-K over many donors
+        ("conv_gn_8_n1280", case_conv_gn, dict(N=1280, C1=64, conv=(36, 8, 8)), TOL_BF16),
+        ("conv_gn_8_concat_res_gnout", case_conv_gn, dict(N=1280, C1=64, C2=32, conv=(36, 8, 8), res=1, gn_out=True, seed=11), TOL_BF16),
+        ("conv_gn_8_add_gnout_streamk", case_conv_gn, dict(N=1280, C1=1280, conv=(36, 8, 8), add=True, gn_out=True, seed=12, expect_streamk=True), TOL_BF16),
+        ("conv_gn_8_three_images", case_conv_gn, dict(N=320, C1=64, conv=(3, 8, 8), res=1, gn_out=True, mean=20.0, seed=13), TOL_BF16),
+        ("conv_gn_unsupported_8x8_four_images", case_conv_gn, dict(N=1280, C1=64, conv=(4, 8, 8), expect_fused=False), TOL_BF16),
         ("convt_gn_T6", case_conv_gn, dict(N=320, C1=64, convt=(2, 6, 1024), res=1, coef=True, seed=7), TOL_BF16),
         ("convt_gn_T18_add_gnout", case_conv_gn, dict(N=320, C1=96, convt=(2, 18, 256), add=True, gn_out=True, seed=8), TOL_BF16),
         ("convt_gn_T12_n640", case_conv_gn, dict(N=640, C1=64, convt=(1, 12, 64), res=1, seed=9), TOL_BF16),

@@ -89,6 +89,8 @@ def build_cases(hip0, only):
     conv("c3_L1_concat1920", 640, 1280, 640, conv=(36, 32, 32), add=True)
     conv("c3_L2_1280_out", 1280, 1280, conv=(36, 16, 16), res=True)
     conv("c3_L2_concat2560", 1280, 1280, 1280, conv=(36, 16, 16), add=True)
+    conv("c3_L3_1280_out", 1280, 1280, conv=(36, 8, 8), res=True)                   # W = 8 haloed kernel: 48 tiles, stream-K over 5-6 blocks per tile
+    conv("c3_L3_concat2560", 1280, 1280, 1280, conv=(36, 8, 8), add=True)
     conv("ct_L0_320_gnin", 320, 320, convt=(2, 18, 4096), res=True, gn_out=False)
     conv("ct_L0_320_plain", 320, 320, convt=(2, 18, 4096), add=True, gn_out=False, gn_in=False)     # v3 CONVT3
     conv("ct_L1_640_plain", 640, 640, convt=(2, 18, 1024), res=True, gn_out=False, gn_in=False)

@@ -24,6 +24,9 @@
 #define E4_ASM_READS 0        // this file chooses the epilogue's LDS read form per kernel (CONV_TEMP_READS below); gn_flush keeps the compiler-visible reads
 #include "gemm_common.h"
 
+#ifndef CONV_3X3_READS
+#define CONV_3X3_READS 0       // ... of the 3 x 3 haloed kernels: measured -1 ... +6 % per launch with the lean asm form (2), see the call
+#endif
 #ifndef CONV_TEMP_READS
 #define CONV_TEMP_READS 2      // e4_fragment read form of the temporal haloed kernels (A/B: -DCONV_TEMP_READS=0)
 #endif
@@ -48,7 +51,11 @@ struct HaloGeom {
     static constexpr int BM = 192, BN = 320;
     static constexpr int NT = HM == HM_CONV ? 9 : 3;                                  // taps = steps per 32-channel chunk
     static constexpr int LINE = HM == HM_CONV ? ((W_ + 2 + 7) / 8) * 8 : 32;          // halo pixels per line (image row / frame)
-    static constexpr int NLINES = HM == HM_CONV ? BM / W_ + 2 : 8;                    // 3x3: tile rows + 2; temporal: 6 frames + 2
+    // W = 8 (round 6): a tile is three WHOLE 8 x 8 images, so the lines above and below it belong to other images and are never read (the
+    // taps that would are masked to the zero page): the halo holds the tile's 24 lines only (TOP = 0) and up to three statistics groups
+    static constexpr int TOP = HM == HM_CONV && W_ == 8 ? 0 : 1;                      // halo lines above the tile's first line
+    static constexpr int NSTAT = HM == HM_CONV && W_ == 8 ? 3 : 2;                    // statistics groups (images) a halo can touch
+    static constexpr int NLINES = HM == HM_CONV ? BM / W_ + 2 * TOP : 8;              // 3x3: tile rows + 2; temporal: 6 frames + 2
     static constexpr int HROWS = NLINES * LINE;
     static constexpr int HPW = ((HROWS + 15) / 16 + 7) / 8;                           // 1-KiB halo pieces per wave
     static constexpr int HBYTES = HPW * 8 * 1024;
@@ -128,8 +135,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     constexpr int WM = 96, WN = 80, MF = 6, NF = 5;
     constexpr int WSTAGE = BN * ROWB;                     // 20 KiB of weights per (chunk, tap) step
     constexpr int EPI_REGION = 16 * (NF * 32 + 16);
+    constexpr int TABB = G::NSTAT * 256;                 // (scale, shift) of a chunk's 32 channels for each statistics group of the halo
     constexpr int RING_OFF = 0, HALO_OFF = NS * WSTAGE, ZERO_OFF = HALO_OFF + NBUF * HBYTES, TAB_OFF = ZERO_OFF + 1024,
-                  EPI_OFF = TAB_OFF + NW * 512 * G::NTAB, SK_OFF = EPI_OFF + NW * EPI_REGION;
+                  EPI_OFF = TAB_OFF + NW * TABB * G::NTAB, SK_OFF = EPI_OFF + NW * EPI_REGION;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[SK_OFF + SK_TAB_BYTES];        // the ONLY __shared__ object
     static_assert(sizeof(lds) <= 160 * 1024, "LDS budget");
 
@@ -203,10 +211,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         int live;          // the cursor is inside this block's tiles
         int fr0;           // 3x3: first flat image row of the tile;  temporal: sample * T + first frame of the tile's frame block
         int frB;           // 3x3: first flat image row of the halo's SECOND statistics group (image);  temporal: position block * 32
+        int frC;           // 3x3, W = 8: first flat image row of the halo's THIRD statistics group
         unsigned statA;    // (scale, shift) rows of the halo's first / last source row
         unsigned statB;
     };
-    HTile ht = {0, 0, 0, 0u, 0u}, xt = {0, 0, 0, 0u, 0u};      // cursor's tile / the tile of the image issued last (picked up by its normalisation chain)
+    HTile ht = {0, 0, 0, 0, 0u, 0u}, xt = {0, 0, 0, 0, 0u, 0u};      // cursor's tile / the tile of the image issued last (picked up by its normalisation chain)
     int h_tab = 0, x_tab = 0;                             // table slot the next issue fills / the last issue filled
     unsigned latch_base = 0;
     // piece i of this wave = halo pixel rows (wave + 8 i) * 16 .. + 15; the lane holds 16 bytes of pixel row + (lane >> 2).  Pieces start at
@@ -226,31 +235,33 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         if (HM == HM_CONV) {
             const int fr0 = tm * (BM / W_);                                    // first flat image row of the tile
             const int nfr = (int)(p.M / W_);
-            const int f_lo = fr0 - 1 < 0 ? 0 : fr0 - 1, f_hi = fr0 + BM / W_ >= nfr ? nfr - 1 : fr0 + BM / W_;
+            const int f_lo = fr0 - G::TOP < 0 ? 0 : fr0 - G::TOP, f_hi = fr0 + BM / W_ - 1 + G::TOP >= nfr ? nfr - 1 : fr0 + BM / W_ - 1 + G::TOP;
             ht.fr0 = fr0;
             ht.statA = (unsigned)((long long)f_lo * W_ / rps);
             ht.statB = (unsigned)((long long)f_hi * W_ / rps);
             ht.frB = (int)(((long long)ht.statA + 1) * rps / W_);
+            ht.frC = (int)(((long long)ht.statA + 2) * rps / W_);
         } else {
             // tile row-block tm = (sample b, frame block tb, position block sb), positions fastest
             const int sb = tm % sblocks, tb = (tm / sblocks) % tblocks, b = tm / (sblocks * tblocks);
             ht.fr0 = b * p.T + tb * 6;
             ht.frB = sb * 32;
+            ht.frC = 0;
             ht.statA = ht.statB = (unsigned)(((long long)b * p.T * p.S) / rps);          // one statistics group per sample (the 3-D GroupNorm)
         }
     };
     // source pixel row of this lane's halo pixel of piece i in tile t (kInvalid: padding / outside the tensor); second = it belongs to statB
     // (ln = an OPAQUE copy of the lane id, made where the rows are needed: as loop invariants the pieces' (line, x) pairs were hoisted in front of
     // the main loop, a dozen registers held through every step - or, once the loop was a register short, re-read from scratch inside it)
-    auto halo_row = [&](const HTile& t, int i, bool& second, int ln) __attribute__((always_inline)) -> unsigned {
+    auto halo_row = [&](const HTile& t, int i, int& second, int ln) __attribute__((always_inline)) -> unsigned {
         const int hp = (wave + NW * i) * 16 + (ln >> 2);
-        second = false;
+        second = 0;
         if (HM == HM_CONV) {
             const int line = hp / LINE, x = hp - line * LINE - 1;
-            const int fr = t.fr0 - 1 + line;
+            const int fr = t.fr0 - G::TOP + line;
             const int nfr = (int)(p.M / W_);
             const bool ok = t.live && x >= 0 && x < W_ && fr >= 0 && fr < nfr && line < G::NLINES;
-            second = fr >= t.frB;
+            second = (fr >= t.frB ? 1 : 0) + (G::NSTAT > 2 && fr >= t.frC ? 1 : 0);       // statistics group of the line, relative to statA
             return ok ? (unsigned)(fr * W_ + x) : kInvalid;
         } else {
             const int line = hp >> 5, sp = hp & 31;
@@ -270,11 +281,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         const bool second = h_c >= k1chunks;
         const int cc = second ? h_c - k1chunks : h_c;
         const unsigned ld2 = (unsigned)((second ? p.lda2 : p.lda) * 2);
-        if (XF && lane < 32) {
-            // (scale, shift) of this chunk's 32 channels for the (at most two) statistics groups of the halo: 2 x 256 B
-            const unsigned st = lane < 16 ? ht.statA : ht.statB;
+        if (XF && lane < 16 * G::NSTAT) {
+            // (scale, shift) of this chunk's 32 channels for the (at most NSTAT) statistics groups of the halo: NSTAT x 256 B
+            const unsigned sg = ht.statA + (unsigned)(lane >> 4);
+            const unsigned st = G::NSTAT == 2 ? (lane < 16 ? ht.statA : ht.statB) : (sg < ht.statB ? sg : ht.statB);
             const unsigned vo = (unsigned)(((long long)st * p.K + (long long)h_c * 32) * 8) + (unsigned)(lane & 15) * 16u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (__attribute__((address_space(3))) void*)(lds + TAB_OFF + (wave * G::NTAB + h_tab) * 512), 16, (int)(ht.live ? vo : kInvalid), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (__attribute__((address_space(3))) void*)(lds + TAB_OFF + (wave * G::NTAB + h_tab) * TABB), 16, (int)(ht.live ? vo : kInvalid), 0, 0, 0);
         }
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
         if (G::NTAB == 2) h_tab ^= 1;
 #pragma unroll
         for (int i = 0; i < HPW; ++i) {
-            bool second_stat;
+            int second_stat;
             const unsigned row = halo_row(ht, i, second_stat, ln);
             const unsigned vo = row == kInvalid ? kInvalid : (CABL(65536) ? (row & 1023u) : row) * ld2 + (unsigned)hchunkpos * 16u;     // (65536: L2-hot source rows)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rsA2 : rsA1, (__attribute__((address_space(3))) void*)(lds + HALO_OFF + h_buf * HBYTES + (wave + NW * i) * 1024), 16,
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     // ---------------------------------------------------------------- the in-place normalisation of the image the loader filled last
     // image being normalised: the one issue_halo wrote at the last issue step
     unsigned xf_base = 0;                                 // LDS byte address of that image
-    HTile ct = {0, 0, 0, 0u, 0u};                         // its tile
+    HTile ct = {0, 0, 0, 0, 0u, 0u};                         // its tile
     int c_tab = 0;                                        // its table slot
     XfState xs;
     auto xf_read_vec = [&](int v) __attribute__((always_inline)) -> u32x4 {
@@ -349,9 +361,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             } else {
                 { unsigned pk = pack2bf(xs.y0, xs.y1); asm volatile("" : "+v"(pk)); xs.out[e] = pk; }
                 if constexpr (e == 3) {
-                    const unsigned wa = lds_addr(lds) + xf_base + hvec0 + v * 8192;
+                    // (the piece's 8-KiB stride rides in the instruction's offset field: as separate per-lane sums the three addresses were hoisted out of the
+                    // loop and - once the kernel was a register short - reloaded from scratch inside it, each reload behind a vmcnt(0))
+                    const unsigned wa = lds_addr(lds) + xf_base + hvec0;
                     const u32x4 wv = xs.out;
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(wa), "v"(wv) : "memory");
+                    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wa), "v"(wv), "n"(v * 8192) : "memory");
                 }
             }
         }
@@ -365,9 +379,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             asm volatile("" : "+v"(ln));
 #pragma unroll
             for (int v = 0; v < HPW; ++v) {
-                bool second;
+                int second;
                 const unsigned row = halo_row(ct, v, second, ln);
-                ctab[v] = (row == kInvalid ? (unsigned)ZERO_OFF : (unsigned)(TAB_OFF + (wave * G::NTAB + c_tab) * 512) + (second ? 256u : 0u)) + (unsigned)hchunkpos * 64u;
+                ctab[v] = (row == kInvalid ? (unsigned)ZERO_OFF : (unsigned)(TAB_OFF + (wave * G::NTAB + c_tab) * TABB) + (unsigned)second * 256u) + (unsigned)hchunkpos * 64u;
             }
             xs.raw = xf_read_vec(0);
             xs.tab = xf_read_tab(0, 0);
@@ -395,13 +409,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
     unsigned faddr[NDX];
 #pragma unroll
     for (int dx = 0; dx < NDX; ++dx) {
-        const int hp = (lane & 15) + dx;
+        // (W = 8: a fragment's 16 rows are two image lines of 8 pixels - lanes 8 .. 15 of a 16-lane group sit one halo line further; bit 2 of the pixel row, which
+        // the swizzle keys on, and the row's bank class mod 4 are what they would be for 16 consecutive pixels)
+        const int hp = HM == HM_CONV && W_ == 8 ? (lane & 7) + dx + ((lane >> 3) & 1) * LINE : (lane & 15) + dx;
         faddr[dx] = (unsigned)(HALO_OFF + hp * 64 + (((lane >> 4) ^ hswz(hp)) * 16));
     }
     auto foff = [&](int i) __attribute__((always_inline)) -> unsigned {
         const int r = wm * WM + i * 16;
-        return (unsigned)((HM == HM_CONV ? (r / W_) * LINE + (r % W_) : r) * 64);
+        return (unsigned)((HM == HM_CONV ? (r / W_ + G::TOP - 1) * LINE + (r % W_) : r) * 64);      // (TOP = 0: line - 1 + dy; the dy = 0 tap of tile line 0 is masked)
     };
+    const bool upper_half = HM == HM_CONV && W_ == 8 && ((lane >> 3) & 1);      // W = 8: the lane's pixel is in the fragment's second image line
     const unsigned zfrag = (unsigned)(ZERO_OFF + (lane & 15) * 64 + (lane >> 4) * 16);
     int c_buf = 0;                                        // halo image of the chunk being consumed (its offset is folded into faddr)
     unsigned vmask = 0;                                   // 3x3: bit (2 i) = fragment i may use dy = 0, bit (2 i + 1) = dy = 2 (same image)
@@ -443,8 +460,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             for (int i = 0; i < MF; ++i) {
                 const int fr = (int)(((long long)tm * BM + wm * WM + i * 16) / W_);
                 const int y = fr % H;
+                // (W = 8: the fragment is the image lines y and y + 1, y even - only its first line can lack the line above, only its second the line below)
                 vmask |= (y > 0 ? 1u : 0u) << (2 * i);
-                vmask |= (y < H - 1 ? 1u : 0u) << (2 * i + 1);
+                vmask |= (y + (W_ == 8 ? 1 : 0) < H - 1 ? 1u : 0u) << (2 * i + 1);
             }
             vmask = (unsigned)__builtin_amdgcn_readfirstlane((int)vmask);
         }
@@ -466,7 +484,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
                         // pixel range, one v_add per fragment - removes 2 v_readlane + 1 v_cndmask per fragment and step and measured 4-8 % SLOWER)
                         unsigned a = fb + foff(i);
                         if (HM == HM_CONV && dy != 1) {
-                            const bool ok = (vmask >> (2 * i + (dy == 2 ? 1 : 0))) & 1u;
+                            bool ok = (vmask >> (2 * i + (dy == 2 ? 1 : 0))) & 1u;
+                            if (W_ == 8) ok = ok || (upper_half != (dy == 2));      // (per lane: the other image line of the fragment has its neighbour inside the image)
                             a = ok ? a : zfrag - (unsigned)(dy * LINE * 64);
                         }
                         xf[i] = *reinterpret_cast<const bf16x8*>(lds + a + dy * LINE * 64);
@@ -575,9 +594,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(GP p, int ntiles) {
             asm volatile("" : "+v"(lane_e));
             const SkItem done = item_at(it);          // (re-read: role / donors are not carried through the chunk loop)
             if (done.role == 2) sk_gather<MF, NF>(p, acc, done.d0, done.d1, wave, lane_e, Gd);
-            // staging reads of the epilogue (gemm_common.h e4_fragment RD): the temporal kernels take the lean asm form; the 3 x 3 kernels sit at 256 registers and
-            // spill inside their main loops with either asm form (tools/check_loop_scratch.py) - they keep the compiler-visible reads and their vmcnt(0) drains
-            e4_retire_tile<MF, NF, GN, E4_DEPTH, (HM == HM_TEMP ? CONV_TEMP_READS : 0)>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
+            // staging reads of the epilogue (gemm_common.h e4_fragment RD): the temporal kernels take the lean asm form (one piece per LDS round trip: -6 %).  The 3 x 3
+            // kernels keep the compiler-visible reads and their vmcnt(0) drains: once the in-place ds_write of the normalisation chain had freed their registers the
+            // lean form fits all but the <W = 32, GroupNorm operand, no statistics> variant (tools/check_loop_scratch.py), but with 90-360 steps per tile the
+            // drains are not what their epilogue costs - -DCONV_3X3_READS=2 measured +-1 % on five launch classes and +6 % on one (profiles/r06_conv_w8_ab.txt)
+            e4_retire_tile<MF, NF, GN, E4_DEPTH, (HM == HM_TEMP ? CONV_TEMP_READS : (W_ == 32 && XF && !GN ? 0 : CONV_3X3_READS))>(p, acc, nw0, lane_e, estage, rowfn, flushfn);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -610,6 +631,12 @@ int v3d_conv_halo_variant(const V3dGemmParams& p, int mode) {
         if (p.stride != 1 || p.upshift != 0 || p.pad_lo != 1 || p.Hin != p.Hout || p.Win != p.Wout) return 0;
         if (p.M % 192) return 0;
         const int W = p.Wout, H = p.Hout;
+        if (W == 8) {
+            // three whole 8 x 8 images per tile: no line of another image is ever needed; one statistics group per image
+            if (H != 8 || (p.gn_in && p.gn_in_rps != 64)) return 0;
+            if (p.gn_stats && p.gn_nslots < p.gn_rps / 96 + 2) return 0;
+            return 5;
+        }
         if (W != 64 && W != 32 && W != 16) return 0;
         if (H < 192 / W + 1) return 0;                              // a halo (tile rows + 2 lines) touches at most two images
         if (p.gn_in && p.gn_in_rps != (long long)H * W) return 0;   // one (scale, shift) row per image: the 2-D GroupNorm of the ResBlocks
@@ -650,6 +677,7 @@ int v3d_conv_halo_launch(const V3dGemmParams& p, int variant, void* stream) {
         case 2: return conv_halo_launch_t<HM_CONV, 32>(p, st);
         case 3: return conv_halo_launch_t<HM_CONV, 16>(p, st);
         case 4: return conv_halo_launch_t<HM_TEMP, 32>(p, st);
+        case 5: return conv_halo_launch_t<HM_CONV, 8>(p, st);
     }
     v3d_set_error("v3d_gemm(haloed): unknown variant %d", variant);
     return V3D_ERR_ARG;

@@ -65,11 +65,14 @@ def _gn_producer(ops, n_stat, rps, cout, device, groups=32, level=1, imgs_per_st
 # GroupNorm + SiLU in the operand path of the convolution that consumes it (v3d_gemm gn_in_table: the LDS-haloed kernels of conv.hip
 # normalise their input tile on its way into LDS).  V3D_CONV_GN=0 restores "v3d_groupnorm_apply, then the convolution" everywhere (A/B knob).
 _CONV_GN = os.environ.get("V3D_CONV_GN", "1") not in ("", "0")
+_HALO8 = os.environ.get("V3D_CONV_HALO8", "0") not in ("", "0")
 
 
 def _halo_level(g: "Geo") -> bool:
-    """Levels the LDS-haloed 3x3 kernels exist for (conv.hip: W in {64, 32, 16})."""
-    return _CONV_GN and g.W in (16, 32, 64)
+    """Levels the LDS-haloed 3x3 kernels run (conv.hip: W in {64, 32, 16}).  The kernel also exists for 8 x 8 images, three to a tile (round 6), and is
+    correct there, but its 48 tiles need a stream-K hand-off over 5-6 blocks per tile: 133 us against ~115 us for the one-launch norm + split-K
+    convolution, 12.49 vs 12.55 frames/s end to end (profiles/r06_conv_w8_ab.txt) - V3D_CONV_HALO8=1 switches it on."""
+    return _CONV_GN and (g.W in (16, 32, 64) or (_HALO8 and g.W == 8 and g.H == 8 and g.n % 3 == 0))
 
 
 def _small_norm(ops, g: "Geo", cout, imgs_per_stat=1) -> bool:
@@ -90,7 +93,7 @@ def conv3x3_gn(ops, x1, x2, norm, w, bias, g: "Geo", *, stats=None, out=None, **
     table = ops.groupnorm_table(x1, x2, ga, be, n, S, eps=eps, stats=stats)
     N = w.shape[-2]
     K = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
-    if _CONV_GN:
+    if _CONV_GN and (g.W != 8 or _halo_level(g)):          # (the library also takes 8 x 8 images since round 6: policy, see _halo_level)
         if out is None:
             out = ops.empty((n * S, N), ops.act_dtype, x1.device)
         call = GemmCall(A=x1, A2=x2, W=w, out=out, M=n * S, N=N, K=K, bias=bias, mode=GEMM_CONV3X3, Hin=g.H, Win=g.W, Hout=g.H, Wout=g.W,
