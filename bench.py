@@ -246,6 +246,31 @@ class _Timed:
         return fam
 
 
+def live_clock_probe():
+    """Shader clock this chip holds with every SIMD issuing MFMAs back to back (v3d_debug_clock_probe: s_memtime against the 100 MHz s_memrealtime, ~10 ms of
+    v_mfma_f32_16x16x32_bf16 on random operands, two waves per SIMD, no memory traffic).  Round 6 saw 12.0 and 12.85 frames/s from ONE library on boxes of one pool:
+    this number says which kind of box a run was on.  None if the library lacks the entry (an older build)."""
+    import ctypes
+    from v3d_amd.ops import get_ops
+    lib = get_ops().lib
+    if not hasattr(lib, "v3d_debug_clock_probe"):
+        return None
+    fn = lib.v3d_debug_clock_probe
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    out = torch.zeros(8, dtype=torch.int64, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    best = None
+    for iters in (20000, 60000, 60000):          # a warm-up launch (the clock takes milliseconds to settle under load), then two measured ones
+        if fn(iters, ctypes.c_void_p(out.data_ptr()), stream) != 0:
+            return None
+        torch.cuda.synchronize()
+        c0, c1, r0, r1 = [int(v) for v in out[:4].tolist()]
+        if r1 > r0:
+            best = {"ghz": round((c1 - c0) / ((r1 - r0) * 10.0), 3), "window_ms": round((r1 - r0) * 1e-5, 2)}
+    return best
+
+
 def measure_rooflines(step):
     """One extra instrumented sample: HIP events around every timed op launch on the launch stream."""
     from v3d_amd.ops import get_ops
@@ -287,7 +312,9 @@ def measure_rooflines(step):
             # context, not the contract's `frac`: the shader clock measured inside a full-occupancy MFMA main loop on this chip (tools/clock_probe.py:
             # s_memtime against the 100 MHz s_memrealtime) is 1.77 GHz with all 256 CUs busy (2.41 GHz with 16) - `peak` above is the 2.4 GHz figure
             "sustained_clock_context": {"ghz_all_cus_busy": 1.773, "ghz_16_cus_busy": 2.407, "bf16_dense_peak_at_that_clock_tflops": 1859.0,
-                                        "frac_of_that": round(achieved / 1859.0, 4), "source": "profiles/r06_clock_probe.txt (recorded; not re-measured by bench.py)"},
+                                        "frac_of_that": round(achieved / 1859.0, 4), "source": "profiles/r06_clock_probe.txt (recorded inside the fused feed-forward)",
+                                        # measured on THIS box right now (MFMA-only probe kernel: an upper bound of the clock under the real kernels, comparable box to box)
+                                        "live_mfma_probe": live_clock_probe()},
             "per_kernel": per}
 
 

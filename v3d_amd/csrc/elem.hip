@@ -480,3 +480,60 @@ extern "C" int v3d_copy2d_bf16(const void* src, int64_t lds, void* dst, int64_t 
                        (long long)rows, (long long)(C / 8));
     return v3d_check_launch("v3d_copy2d_bf16");
 }
+
+// ---- measurement aid (bench.py `box` object; not part of the product path): which shader clock does THIS chip hold when every SIMD issues MFMAs back to back?
+// Round 6 measured 1.77 GHz on some boxes of the pool and 1.61 GHz on others (same day, same binaries: profiles/r06_clock_probe*.txt) and the end-to-end number
+// follows that clock.  Two 4-wave blocks per CU (two waves per SIMD, the occupancy of the persistent kernels) run `iters` rounds of eight independent
+// v_mfma_f32_16x16x32_bf16 on pseudo-random operands in [0.5, 1) (constant data clocks higher); block 0 stamps s_memtime (shader cycles) and s_memrealtime (100 MHz)
+// around its loop: out[0..3] = cycles0, cycles1, real0, real1.  Operand fragments come from LDS every round (6 ds_read_b128 per 8 MFMAs), no global memory traffic:
+// an upper bound of the clock under the real kernels, comparable box to box.
+namespace {
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* out, int iters, unsigned seed) {
+    __shared__ u32x4 frag[6 * 256];                          // the operand fragments: six 16-byte vectors per thread, re-read every round
+    unsigned s = seed ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+    auto rnd = [&]() -> unsigned {
+        s = s * 1664525u + 1013904223u;
+        return ((s >> 7) & 0x807f807fu) | 0x3f003f00u;      // two bf16 with random sign and mantissa, exponent of 0.5
+    };
+#pragma unroll
+    for (int i = 0; i < 6; ++i) frag[i * 256 + threadIdx.x] = u32x4{rnd(), rnd(), rnd(), rnd()};
+    __syncthreads();
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long c0 = 0, r0 = 0;
+    if (stamp) {
+        c0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    int idx = threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(idx));                       // (opaque: the six reads stay inside the loop - 6 ds_read_b128 per 8 MFMAs, the mix of the GEMM main loops)
+        bf16x8 a[2], b[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = __builtin_bit_cast(bf16x8, frag[i * 256 + idx]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(bf16x8, frag[(2 + i) * 256 + idx]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j & 1], b[j >> 1], acc[j], 0, 0, 0);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (stamp) {
+        out[0] = c0;
+        out[1] = __builtin_amdgcn_s_memtime();
+        out[2] = r0;
+        out[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (sum == 123.456f) out[4] = 1;      // (keeps the accumulators live)
+}
+}  // namespace
+
+// debug / measurement entry (not declared in include/v3d_hip.h, like the other v3d_debug_* symbols): out = 5 x uint64 on the device
+extern "C" int v3d_debug_clock_probe(int iters, unsigned long long* out, v3d_stream_t stream) {
+    V3D_REQUIRE(out && iters > 0, "v3d_debug_clock_probe: bad args");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(2 * v3d_num_cus()), dim3(256), 0, ST, out, iters, 12345u);
+    return v3d_check_launch("v3d_debug_clock_probe");
+}
