@@ -246,6 +246,14 @@ class _Timed:
         return fam
 
 
+def _safe(fn):
+    """context values must never cost the run its metric line"""
+    try:
+        return fn()
+    except Exception as e:      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def live_clock_probe():
     """Shader clock this chip holds with every SIMD issuing MFMAs back to back (v3d_debug_clock_probe: s_memtime against the 100 MHz s_memrealtime, ~10 ms of
     v_mfma_f32_16x16x32_bf16 on random operands, two waves per SIMD, no memory traffic).  Round 6 saw 12.0 and 12.85 frames/s from ONE library on boxes of one pool:
@@ -314,7 +322,7 @@ def measure_rooflines(step):
             "sustained_clock_context": {"ghz_all_cus_busy": 1.773, "ghz_16_cus_busy": 2.407, "bf16_dense_peak_at_that_clock_tflops": 1859.0,
                                         "frac_of_that": round(achieved / 1859.0, 4), "source": "profiles/r06_clock_probe.txt (recorded inside the fused feed-forward)",
                                         # measured on THIS box right now (MFMA-only probe kernel: an upper bound of the clock under the real kernels, comparable box to box)
-                                        "live_mfma_probe": live_clock_probe()},
+                                        "live_mfma_probe": _safe(live_clock_probe)},
             "per_kernel": per}
 
 
