@@ -779,7 +779,7 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
         if ((NP % 64 == 0 || c < NP) && !V3D_ABL(p, 1)) *reinterpret_cast<u32x4*>(outz + (long long)row * p.ldo + ch * 8) = sr;
     }
     } else {
-    // (RD = 0: compiler-visible reads - the 3 x 3 LDS-haloed kernels of conv.hip sit at 256 registers and spill inside their main loops with either asm form)
+    // (RD = 0: compiler-visible reads, each behind the compiler's vmcnt(0) - the 3 x 3 LDS-haloed kernels of conv.hip: their tiles are 90-360 steps long and the asm forms measured +-1 %)
     if (has1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
@@ -821,8 +821,10 @@ __device__ __forceinline__ void e4_fragment(const GP& p, f32x4 (&acc)[NF], long 
 #ifndef E4_DEPTH_LINEAR
 #define E4_DEPTH_LINEAR 1
 #endif
+// (v6 ran depth 2 while the compiler's drains were in place: -2 % then; with the asm staging reads depth 1 measures the same or 1-3 % better per launch and
+// keeps one set of in-flight registers less in rotation - profiles/r06_e4_asm_reads_ab.txt)
 #ifndef E4_DEPTH_V6
-#define E4_DEPTH_V6 2
+#define E4_DEPTH_V6 1
 #endif
 template <int NF>
 struct E4Cnt {
